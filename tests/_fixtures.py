@@ -1,0 +1,98 @@
+"""Loaders for tests/golden/* (vectors produced by tools/gen_golden.py from the reference)."""
+import json
+import os
+
+import numpy as np
+import scipy.sparse as sp
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def load_json(name):
+    with open(os.path.join(GOLDEN, name)) as f:
+        return json.load(f)
+
+
+def load_npz(name):
+    return dict(np.load(os.path.join(GOLDEN, name)))
+
+
+def split_state(npz):
+    g = {k[2:]: v for k, v in npz.items() if k.startswith('g.')}
+    h = {k[2:]: v for k, v in npz.items() if k.startswith('h.')}
+    return g, h
+
+
+class GoldenRoadWorld(object):
+    """The small 'messy' 16x16 street grid + road model every search golden was made on."""
+
+    def __init__(self):
+        self.net = load_json('road_net.json')
+        self.npz = load_npz('road_model.npz')
+        self.g_state, self.h_state = split_state(self.npz)
+        self.w1 = float(self.npz['w1'][0])
+        self.n = self.net['num_roads']
+        self.adjacent_list = self.net['adjacent_list']
+        self.rid_gps = self.net['rid_gps']
+        self.road_length = self.net['road_length']
+        self.rtd = self.npz['rtd']
+        self.node_features = self.npz['node_features']
+        self.edge_index = self.npz['edge_index']
+        self.cfg = load_json('g234_predict.json')['config']
+
+    def adj_mx(self):
+        ei = self.edge_index
+        return sp.coo_matrix((np.ones(ei.shape[1], dtype=np.float32), (ei[0], ei[1])),
+                             shape=(self.n + 1, self.n + 1))
+
+    def data_feature(self, torch):
+        return {'road_num': self.n + 1, 'time_size': 2881, 'road_pad': self.n, 'time_pad': 2880,
+                'adj_mx': self.adj_mx(), 'node_features': torch.as_tensor(self.node_features),
+                'img_width': self.net['img_width'], 'img_height': self.net['img_height']}
+
+    def oracle_model(self):
+        from oracle.model import OracleGenerator
+        fh = self.cfg['function_h']
+        return OracleGenerator(self.g_state, self.h_state, self.w1, self.node_features, self.edge_index,
+                               fh['num_of_heads'], fh['embed_dim'], self.cfg['function_g']['lstm_layer_num'],
+                               fh['concat'], fh.get('no_gps_emb', False))
+
+
+class GoldenRegionWorld(object):
+    def __init__(self):
+        self.meta = load_json('g7_double_layer.json')
+        self.npz = load_npz('region_model.npz')
+        self.g_state, self.h_state = split_state(self.npz)
+        self.w1 = float(self.npz['w1'][0])
+        self.cfg = self.meta['config']
+        self.num_regions = self.meta['num_regions']
+        self.node_features = self.npz['node_features']
+        self.edge_index = self.npz['edge_index']
+
+    def adj_mx(self):
+        ei = self.edge_index
+        n = self.num_regions
+        return sp.coo_matrix((np.ones(ei.shape[1], dtype=np.float32), (ei[0], ei[1])), shape=(n + 1, n + 1))
+
+    def data_feature(self, torch):
+        n = self.num_regions
+        return {'road_num': n + 1, 'time_size': 2881, 'road_pad': n, 'time_pad': 2880,
+                'adj_mx': self.adj_mx(), 'node_features': torch.as_tensor(self.node_features),
+                'img_width': 52, 'img_height': 43}
+
+    def oracle_model(self):
+        from oracle.model import OracleGenerator
+        fh = self.cfg['function_h']
+        return OracleGenerator(self.g_state, self.h_state, self.w1, self.node_features, self.edge_index,
+                               fh['num_of_heads'], fh['embed_dim'], self.cfg['function_g']['lstm_layer_num'],
+                               fh['concat'], fh.get('no_gps_emb', False))
+
+    def tables(self, road_world):
+        return {'adjacent_list': road_world.adjacent_list, 'road_center_gps': road_world.rid_gps,
+                'road_length': road_world.road_length,
+                'road_time_distribution': road_world.rtd.astype(int),
+                'region_adjacent_list': self.meta['region_adjacent_list'],
+                'region_dist': self.npz['region_dist'],
+                'region_transfer_freq': self.meta['region_transfer_freq'],
+                'rid2region': self.meta['rid2region'], 'region2rid': self.meta['region2rid'],
+                'region_time_distribution': self.npz['region_time_distribution'].astype(int)}

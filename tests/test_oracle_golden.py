@@ -1,0 +1,104 @@
+"""Pin the CPU oracle against the golden vectors captured from the reference."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import model as om
+from oracle import search as osr
+from tests._fixtures import GoldenRegionWorld, GoldenRoadWorld, load_json, load_npz
+
+RTOL = 1e-5   # oracle vs reference: same torch-CPU fp32 ops, only the op grouping differs
+
+
+@pytest.fixture(scope='module')
+def road():
+    return GoldenRoadWorld()
+
+
+@pytest.fixture(scope='module')
+def region():
+    return GoldenRegionWorld()
+
+
+@pytest.mark.parametrize('case', ['a', 'b', 'c'])
+def test_g1_gat_layer(case):
+    z = load_npz('g1_gat.npz')
+    t = lambda k: torch.as_tensor(z['%s_%s' % (case, k)])
+    nh = z['%s_scoring_fn_source' % case].shape[1]
+    fo = z['%s_scoring_fn_source' % case].shape[2]
+    out = om.gat_forward(t('x'), torch.as_tensor(z['edge_index']), t('linear_proj.weight'), t('skip_proj.weight'),
+                         t('scoring_fn_source'), t('scoring_fn_target'), t('bias'), nh, fo,
+                         concat=bool(z['%s_concat' % case]))
+    np.testing.assert_allclose(out.numpy(), z['%s_out' % case], rtol=RTOL, atol=1e-6)
+
+
+def test_g2_node_embedding(road, region):
+    np.testing.assert_allclose(road.oracle_model().setup_node_emb().numpy(), road.npz['node_emb'],
+                               rtol=RTOL, atol=1e-6)
+    np.testing.assert_allclose(region.oracle_model().setup_node_emb().numpy(), region.npz['node_emb'],
+                               rtol=RTOL, atol=1e-5)
+
+
+def test_g234_predict(road):
+    m = road.oracle_model()
+    for c in load_json('g234_predict.json')['cases']:
+        g = m.predict_g(c['loc'], c['tim'], c['cand']).numpy()
+        h = m.predict_h(c['cand'], c['des'], c['dis']).numpy()
+        p = m.predict(c['loc'], c['tim'], c['des'], c['cand'], np.asarray(c['dis'], dtype=np.float32)).numpy()
+        np.testing.assert_allclose(g, c['g'], rtol=RTOL, atol=1e-7)
+        np.testing.assert_allclose(h, c['h'], rtol=RTOL, atol=1e-7)
+        np.testing.assert_allclose(p, c['p'], rtol=RTOL, atol=1e-7)
+
+
+def _check_search_case(got_loc, got_tim, stats, c):
+    assert got_loc == c['loc']
+    assert got_tim == c['tim']
+    assert [p[0] for p in stats.pops] == c['pop_rid']
+    np.testing.assert_allclose([p[1] for p in stats.pops], c['pop_prio'], rtol=1e-5, atol=1e-6)
+
+
+def test_g5_astar(road):
+    m = road.oracle_model()
+    rtd = road.rtd.astype(int)
+    cases = load_json('g5_astar.json')['cases']
+    kinds = set()
+    for c in cases:
+        st = osr.SearchStats()
+        loc, tim = osr.astar_search(m, road.adjacent_list, road.rid_gps, road.road_length, rtd,
+                                    [c['start']], [c['start_time']], c['des'], c['default_len'], c['max_step'],
+                                    stats=st)
+        _check_search_case(loc, tim, st, c)
+        kinds.add(st.status)
+    assert kinds == {osr.REACHED, osr.FALLBACK, osr.UNTOUCHED}
+
+
+def test_g6_astar_in_region(road, region):
+    m = road.oracle_model()
+    rtd = road.rtd.astype(int)
+    for c in load_json('g6_astar_in_region.json')['cases']:
+        st = osr.SearchStats()
+        rset = set(region.meta['region2rid'][str(c['region'])])
+        loc, tim = osr.astar_search(m, road.adjacent_list, road.rid_gps, road.road_length, rtd,
+                                    c['prefix_loc'], c['prefix_tim'], c['des'], c['default_len'], c['max_step'],
+                                    region_rid_set=rset, stats=st)
+        _check_search_case(loc, tim, st, c)
+
+
+def test_g7_double_layer(road, region):
+    road_m = road.oracle_model()
+    reg_m = region.oracle_model()
+    tables = region.tables(road)
+    fail, rfail = set(), set()
+    for c in region.meta['cases']:
+        rtrace, flag = osr.region_astar_search(reg_m, tables['region_adjacent_list'], tables['region_dist'],
+                                               tables['region_time_distribution'],
+                                               tables['rid2region'][str(c['start'])], c['start_time'],
+                                               tables['rid2region'][str(c['des'])], c['max_step'])
+        assert rtrace == c['region_trace'] and flag == c['region_flag']
+        rng = np.random.RandomState(c['seed'])
+        loc, tim, is_astar = osr.double_layer_astar_search(reg_m, road_m, tables, c['start'], c['start_time'],
+                                                           c['des'], c['default_len'], c['max_step'], rng=rng,
+                                                           fail_log=fail, region_fail_log=rfail)
+        assert loc == c['loc'] and tim == c['tim'] and is_astar == c['is_astar']
+    assert sorted([list(map(int, x)) for x in fail]) == region.meta['fail_find_log']
+    assert sorted([list(map(int, x)) for x in rfail]) == region.meta['region_fail_find_log']

@@ -1,0 +1,346 @@
+"""Generate tests/golden/* by importing the REFERENCE (/root/reference) in the build container.
+
+Run here only (the reference never travels): `python tools/gen_golden.py`.
+The reference's `search.py` does `from geopy import distance` (search.py:7); geopy is absent, so a
+stub module exposing `distance.distance(p, q).kilometers` is injected BEFORE the import and backed
+by oracle/geodesic.py (parity at that boundary is unpinned, see oracle/__init__.py).
+Only inputs and outputs are stored (weights, graphs, probabilities, trajectories, pop traces);
+no reference source text is copied anywhere.
+"""
+import json
+import os
+import queue
+import sys
+import types
+
+os.environ.setdefault('PYTHONDONTWRITEBYTECODE', '1')
+sys.dont_write_bytecode = True
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, '/root/reference')
+
+import numpy as np
+import scipy.sparse as sp
+import torch
+
+from oracle import geodesic
+from ts_trajgen_amd import synth
+
+_geopy = types.ModuleType('geopy')
+_dist = types.ModuleType('geopy.distance')
+_dist.distance = geodesic._Distance
+_geopy.distance = _dist
+sys.modules['geopy'] = _geopy
+sys.modules['geopy.distance'] = _dist
+
+import search as ref_search                                   # noqa: E402
+from generator.gat import GATLayerImp3                        # noqa: E402
+from generator.generator_v4 import GeneratorV4                # noqa: E402
+
+OUT = os.path.join(ROOT, 'tests', 'golden')
+os.makedirs(OUT, exist_ok=True)
+
+
+def sd_np(module, prefix=''):
+    return {prefix + k: v.detach().cpu().numpy() for k, v in module.state_dict().items()}
+
+
+# ----------------------------------------------------------------------------- G1: GAT layer
+def gen_g1():
+    rng = np.random.RandomState(11)
+    n = 65
+    e = 200
+    src = rng.randint(0, n - 5, size=e)          # nodes n-5.. never a source
+    trg = rng.randint(5, n, size=e)              # nodes 0..4 have in-degree 0
+    src[:6] = src[6:12]                          # duplicate edges
+    trg[:6] = trg[6:12]
+    src[12] = trg[12] = 20                       # self loop
+    edge_index = np.stack([src, trg]).astype(np.int64)
+    out = {}
+    for name, fin, fout, concat in (('a', 20, 32, False), ('b', 32, 32, False), ('c', 12, 16, True)):
+        torch.manual_seed(100 + fin)
+        layer = GATLayerImp3(num_in_features=fin, num_out_features=fout, num_of_heads=5, device='cpu',
+                             concat=concat)
+        with torch.no_grad():
+            layer.bias.normal_(0, 0.1)
+        layer.train(False)
+        x = torch.randn(n, fin)
+        with torch.no_grad():
+            y, _ = layer((x, torch.from_numpy(edge_index)))
+        out['%s_x' % name] = x.numpy()
+        out['%s_out' % name] = y.numpy()
+        out['%s_concat' % name] = np.array(int(concat))
+        for k, v in sd_np(layer).items():
+            out['%s_%s' % (name, k)] = v
+    out['edge_index'] = edge_index
+    np.savez_compressed(os.path.join(OUT, 'g1_gat.npz'), **out)
+    print('G1 done')
+
+
+# ----------------------------------------------------------------------------- shared small world
+ROAD_CFG = {
+    'function_g': {'road_emb_size': 32, 'time_emb_size': 8, 'hidden_size': 32, 'dropout_p': 0.6,
+                   'lstm_layer_num': 2, 'pretrain_road_rep': None, 'dis_weight': 0.5, 'device': 'cpu'},
+    'function_h': {'embed_dim': 32, 'gps_emb_dim': 4, 'num_of_heads': 5, 'concat': False, 'device': 'cpu',
+                   'distance_mode': 'l2'},
+    'dis_weight': 0.45,
+}
+REGION_CFG = {
+    'function_g': {'road_emb_size': 16, 'time_emb_size': 8, 'hidden_size': 16, 'dropout_p': 0.6,
+                   'lstm_layer_num': 2, 'pretrain_road_rep': None, 'dis_weight': 0.5, 'device': 'cpu'},
+    'function_h': {'embed_dim': 16, 'gps_emb_dim': 4, 'num_of_heads': 5, 'concat': False, 'device': 'cpu',
+                   'distance_mode': 'l2', 'no_gps_emb': True},
+    'dis_weight': 0.45,
+}
+
+
+def messy_network(seed=5):
+    """16x16 street grid with single-successor roads, dead ends and unreachable roads mixed in."""
+    net = synth.street_grid_network(16, seed=1)
+    rng = np.random.RandomState(seed)
+    n = net.num_roads
+    adj = {k: list(v) for k, v in net.adjacent_list.items()}
+    unreachable = set(rng.choice(n, 4, replace=False).tolist())
+    for k in list(adj.keys()):
+        adj[k] = [c for c in adj[k] if c not in unreachable]
+    for r in rng.choice(n, n // 8, replace=False):
+        if len(adj.get(str(r), [])) > 1:
+            adj[str(r)] = [adj[str(r)][int(rng.randint(len(adj[str(r)])))]]
+    for r in rng.choice(n, n // 30, replace=False):
+        adj.pop(str(r), None)
+    adj = {k: v for k, v in adj.items() if len(v) > 0}
+    rows = [int(k) for k, v in adj.items() for _ in v]
+    cols = [c for k, v in adj.items() for c in v]
+    net.adjacent_list = adj
+    net.adj_mx = sp.coo_matrix((np.ones(len(rows), dtype=np.float32), (rows, cols)), shape=(n + 1, n + 1))
+    net.meta['unreachable'] = sorted(unreachable)
+    return net
+
+
+def build_road_model(net):
+    torch.manual_seed(0)
+    model = GeneratorV4(config=ROAD_CFG, data_feature=net.data_feature(torch))
+    with torch.no_grad():
+        model.function_h.gat_encoder.bias.normal_(0, 0.1)
+        # spread the logits so that the search is not a pure breadth-first sweep
+        model.function_g.out_fc.weight.mul_(8.0)
+        model.function_h.out_fc.weight.mul_(4.0)
+    model.train(False)
+    return model
+
+
+def net_json(net):
+    return {'num_roads': net.num_roads, 'adjacent_list': net.adjacent_list, 'rid_gps': net.rid_gps,
+            'road_length': net.road_length, 'img_width': net.img_width, 'img_height': net.img_height,
+            'unreachable': net.meta.get('unreachable', [])}
+
+
+class RecordingPQ(queue.PriorityQueue):
+    """queue.PriorityQueue that logs every get() as (priority, rid)."""
+    log = None
+
+    def get(self, *a, **kw):
+        item = super().get(*a, **kw)
+        if RecordingPQ.log is not None:
+            RecordingPQ.log.append((float(item[0]), int(item[1].rid)))
+        return item
+
+
+def nonstale(log):
+    seen = set()
+    out = []
+    for p, r in log:
+        if r not in seen:
+            seen.add(r)
+            out.append((r, p))
+    return out
+
+
+def gen_model_goldens():
+    net = messy_network()
+    model = build_road_model(net)
+    n = net.num_roads
+    rng = np.random.RandomState(7)
+    out = {}
+    for k, v in sd_np(model.function_g).items():
+        out['g.' + k] = v
+    for k, v in sd_np(model.function_h).items():
+        out['h.' + k] = v
+    out['w1'] = model.w1.detach().numpy()
+    out['node_features'] = net.node_features
+    out['edge_index'] = np.stack([net.adj_mx.row, net.adj_mx.col]).astype(np.int64)
+    out['rtd'] = net.road_time_distribution
+    with torch.no_grad():
+        model.function_h._setup_node_emb()
+        out['node_emb'] = model.function_h.node_emb_feature.numpy()                      # G2 (GAT through H)
+        # G2/G3/G4 cases: random prefixes that follow the adjacency, candidates = successors
+        cases = []
+        keys = [int(k) for k in net.adjacent_list.keys() if len(net.adjacent_list[k]) > 1]
+        for ci in range(32):
+            L = 1 + ci % 12
+            r = int(keys[rng.randint(len(keys))])
+            loc = [r]
+            while len(loc) < L:
+                nb = net.adjacent_list.get(str(loc[-1]))
+                if not nb:
+                    break
+                loc.append(int(nb[rng.randint(len(nb))]))
+            if str(loc[-1]) not in net.adjacent_list or len(net.adjacent_list[str(loc[-1])]) < 2:
+                loc = loc[:1]
+            t0 = int(rng.randint(0, 2880))
+            tim = [min(t0 + i, 2879) for i in range(len(loc))]
+            cand = net.adjacent_list[str(loc[-1])]
+            des = int(rng.randint(n))
+            dis = [geodesic.candidate_dis(net.rid_gps[str(des)], net.rid_gps[str(c)]) for c in cand]
+            tl = torch.LongTensor(loc).unsqueeze(0)
+            tt = torch.LongTensor(tim).unsqueeze(0)
+            cs = torch.LongTensor(cand).unsqueeze(0)
+            cd = torch.FloatTensor(dis).unsqueeze(0)
+            dt = torch.LongTensor([des])
+            g = model.function_g.predict_g(tl, tt, dt, cs, cd)
+            h = model.function_h.predict_next(cs, dt, cd)
+            p = model.predict(trace_loc=tl, trace_time=tt, des=dt, candidate_set=cs, candidate_dis=cd)
+            cases.append({'loc': loc, 'tim': tim, 'des': des, 'cand': [int(c) for c in cand],
+                          'dis': [float(np.float32(d)) for d in dis],
+                          'g': g.squeeze(0).tolist(), 'h': h.squeeze(0).tolist(), 'p': p.squeeze(0).tolist(),
+                          'logp': torch.log(p).squeeze(0).tolist()})
+    np.savez_compressed(os.path.join(OUT, 'road_model.npz'), **out)
+    with open(os.path.join(OUT, 'road_net.json'), 'w') as f:
+        json.dump(net_json(net), f)
+    with open(os.path.join(OUT, 'g234_predict.json'), 'w') as f:
+        json.dump({'config': ROAD_CFG, 'cases': cases}, f)
+    print('G2-G4 done')
+    return net, model
+
+
+# ----------------------------------------------------------------------------- G5/G6: road A*
+def gen_search_goldens(net, model):
+    ref_search.PriorityQueue = RecordingPQ
+    searcher = ref_search.Searcher('cpu', net.adjacent_list, net.rid_gps, net.road_length,
+                                   net.road_time_distribution)
+    n = net.num_roads
+    rng = np.random.RandomState(9)
+    od = synth.make_od_pairs(net, 64, seed=2)
+    cases = []
+    unreachable = net.meta['unreachable']
+    for i in range(64):
+        o, d, t, dl = int(od['start'][i]), int(od['des'][i]), int(od['start_time'][i]), int(od['default_len'][i])
+        max_step = 5000
+        if i % 8 == 3:
+            max_step = int(rng.randint(3, 40))               # budget exhausted -> fallback / untouched
+        if i % 16 == 5:
+            d = int(unreachable[i % len(unreachable)])       # des with no incoming edge
+            dl = int(rng.randint(3, 12))
+        if i == 10:
+            d = o                                            # start == des
+        if i % 4 == 1:
+            dl = int(rng.randint(2, 9))                      # short default_len: exercises the fallback snapshot
+        RecordingPQ.log = []
+        with torch.no_grad():
+            loc, tim = searcher.astar_search(model, [o], [t], d, dl, max_step=max_step)
+        pops = nonstale(RecordingPQ.log)
+        cases.append({'start': o, 'start_time': t, 'des': d, 'default_len': dl, 'max_step': max_step,
+                      'loc': [int(x) for x in loc], 'tim': [int(x) for x in tim],
+                      'pop_rid': [p[0] for p in pops], 'pop_prio': [p[1] for p in pops]})
+    with open(os.path.join(OUT, 'g5_astar.json'), 'w') as f:
+        json.dump({'cases': cases}, f)
+    print('G5 done', sum(c['loc'][-1] == c['des'] for c in cases), 'reached of', len(cases))
+
+    # G6: in-region search continuing a multi-element prefix
+    rt = synth.region_tables(net, tiles=2)
+    cases6 = []
+    for i in range(16):
+        base = cases[(i * 3) % 64]
+        if len(base['loc']) < 4:
+            continue
+        k = 2 + i % 3
+        prefix_loc, prefix_tim = base['loc'][:k], base['tim'][:k]
+        reg = rt['rid2region'][str(prefix_loc[-1])]
+        region_set = set(rt['region2rid'][str(reg)])
+        members = sorted(region_set)
+        d = int(members[rng.randint(len(members))]) if i % 2 == 0 else int(rng.randint(n))
+        dl = int(rng.randint(k + 1, k + 10))
+        RecordingPQ.log = []
+        with torch.no_grad():
+            loc, tim = searcher.astar_search_in_region(model, prefix_loc, prefix_tim, d, dl, region_set,
+                                                       max_step=300)
+        pops = nonstale(RecordingPQ.log)
+        cases6.append({'prefix_loc': prefix_loc, 'prefix_tim': prefix_tim, 'des': d, 'default_len': dl,
+                       'region': int(reg), 'max_step': 300, 'loc': [int(x) for x in loc],
+                       'tim': [int(x) for x in tim], 'pop_rid': [p[0] for p in pops],
+                       'pop_prio': [p[1] for p in pops]})
+    with open(os.path.join(OUT, 'g6_astar_in_region.json'), 'w') as f:
+        json.dump({'tiles': 2, 'cases': cases6}, f)
+    print('G6 done', len(cases6))
+    return rt
+
+
+# ----------------------------------------------------------------------------- G7: two-stage
+def gen_double_layer(net, model, rt):
+    nreg = rt['num_regions']
+    n = net.num_roads
+    with torch.no_grad():
+        node_emb = model.function_h.node_emb_feature
+        mat = np.zeros((nreg, n))
+        for rid, reg in rt['rid2region'].items():
+            mat[reg][int(rid)] = 1.0
+        region_feature = torch.matmul(torch.FloatTensor(mat), node_emb)     # prepare_region_feature.py:69-75
+    region_df = {'road_num': nreg + 1, 'time_size': 2881, 'road_pad': nreg, 'time_pad': 2880,
+                 'adj_mx': rt['region_adj_mx'], 'node_features': region_feature, 'img_width': 52, 'img_height': 43}
+    torch.manual_seed(1)
+    region_model = GeneratorV4(config=REGION_CFG, data_feature=region_df)
+    with torch.no_grad():
+        region_model.function_h.gat_encoder.bias.normal_(0, 0.1)
+        region_model.function_g.out_fc.weight.mul_(8.0)
+    region_model.train(False)
+    ref_search.PriorityQueue = queue.PriorityQueue
+    searcher = ref_search.DoubleLayerSearcher('cpu', net.adjacent_list, net.rid_gps, net.road_length,
+                                              rt['region_adjacent_list'], rt['region_dist'],
+                                              rt['region_transfer_freq'], rt['rid2region'], rt['region2rid'],
+                                              net.road_time_distribution, rt['region_time_distribution'])
+    od = synth.make_od_pairs(net, 24, seed=4)
+    cases = []
+    for i in range(24):
+        o, d, t, dl = int(od['start'][i]), int(od['des'][i]), int(od['start_time'][i]), int(od['default_len'][i])
+        np.random.seed(i)
+        with torch.no_grad():
+            loc, tim, is_astar = searcher.astar_search(region_model, model, o, t, d, dl, max_step=400)
+        # the region-level trace alone (same seed state is irrelevant: no RNG in the region stage)
+        with torch.no_grad():
+            rtrace, flag = searcher.astar_search_in_region(region_model, rt['rid2region'][str(o)], t,
+                                                           rt['rid2region'][str(d)], 400)
+        cases.append({'start': o, 'start_time': t, 'des': d, 'default_len': dl, 'max_step': 400, 'seed': i,
+                      'loc': [int(x) for x in loc], 'tim': [int(x) for x in tim], 'is_astar': int(is_astar),
+                      'region_trace': [int(x) for x in rtrace], 'region_flag': int(flag)})
+    out = {}
+    for k, v in sd_np(region_model.function_g).items():
+        out['g.' + k] = v
+    for k, v in sd_np(region_model.function_h).items():
+        out['h.' + k] = v
+    out['w1'] = region_model.w1.detach().numpy()
+    out['node_features'] = region_feature.numpy()
+    out['edge_index'] = np.stack([rt['region_adj_mx'].row, rt['region_adj_mx'].col]).astype(np.int64)
+    with torch.no_grad():
+        region_model.function_h._setup_node_emb()
+        out['node_emb'] = region_model.function_h.node_emb_feature.numpy()
+    out['region_dist'] = rt['region_dist']
+    out['region_time_distribution'] = rt['region_time_distribution']
+    np.savez_compressed(os.path.join(OUT, 'region_model.npz'), **out)
+    with open(os.path.join(OUT, 'g7_double_layer.json'), 'w') as f:
+        json.dump({'config': REGION_CFG, 'tiles': 2, 'num_regions': nreg,
+                   'rid2region': rt['rid2region'], 'region2rid': rt['region2rid'],
+                   'region_adjacent_list': rt['region_adjacent_list'],
+                   'region_transfer_freq': rt['region_transfer_freq'],
+                   'fail_find_log': sorted([[int(a), int(b)] for a, b in searcher.fail_find_log]),
+                   'region_fail_find_log': sorted([[int(a), int(b)] for a, b in searcher.region_fail_find_log]),
+                   'cases': cases}, f)
+    print('G7 done', sum(c['loc'][-1] == c['des'] for c in cases), 'reached of', len(cases))
+
+
+if __name__ == '__main__':
+    gen_g1()
+    net, model = gen_model_goldens()
+    rt = gen_search_goldens(net, model)
+    gen_double_layer(net, model, rt)
+    for fn in sorted(os.listdir(OUT)):
+        print(fn, os.path.getsize(os.path.join(OUT, fn)))
