@@ -1,0 +1,244 @@
+/*
+ * tsg.h -- C ABI of libtsg.so: gfx950 (MI355X) HIP kernels for the A*-guided trajectory
+ * generation path of TS-TrajGen.
+ *
+ * The reference is pure Python on stock PyTorch ops and has NO FFI / plugin layer for this
+ * path, so there is no existing binding to match symbol-for-symbol.
+ * Each entry point below therefore cites the reference *Python* interface it replaces; the
+ * host-side mirror of that interface lives in ts-trajgen_amd/ and is what a maintainer binds
+ * (INTEGRATION.md shows the ctypes stubs).
+ *
+ * Conventions
+ *   - Every pointer is a DEVICE pointer unless its name ends in _host.
+ *   - The caller allocates and owns every buffer, workspaces included; nothing here calls
+ *     hipMalloc/hipFree.  Descriptors carry the byte size of every workspace and the library
+ *     checks them (and all dims) on the host before any launch.
+ *   - All functions only enqueue work on `stream` (a hipStream_t passed as void*); no hidden
+ *     synchronisation, no global mutable state, re-entrant across streams/devices.
+ *   - Return value: 0 on success, a negative TSG_E_* code or -(hipError_t) - 1000 otherwise.
+ *     No C++ exception crosses the boundary.
+ *   - fp32 arithmetic, int32 ids/time codes, fp64 only inside the geodesic distance.
+ */
+#ifndef TSG_H_
+#define TSG_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TSG_ABI_VERSION 1
+
+#define TSG_E_INVALID (-1)   /* bad dims / null pointer / misaligned */
+#define TSG_E_TOO_SMALL (-2) /* a caller-provided buffer is smaller than required */
+#define TSG_E_LIMIT (-3)     /* a documented limit is exceeded (e.g. out-degree > 64) */
+
+#define TSG_MAX_LAYERS 4
+#define TSG_MAX_DEGREE 64 /* successors per road the scoring kernel handles in one wave */
+#define TSG_H_HIDDEN 10   /* emb_fc / dis_fc width, hard-coded at distance_gat_fc.py:38-40 */
+
+/* per-OD result status (mirrors the three exits of search.py:421-424) */
+#define TSG_STATUS_UNTOUCHED 0 /* no best_trace: the input prefix is returned */
+#define TSG_STATUS_REACHED 1   /* destination popped (search.py:291-297) */
+#define TSG_STATUS_FALLBACK 2  /* best path of length default_len (search.py:397-402) */
+#define TSG_STATUS_OVERFLOW 0x100 /* OR-ed in: path longer than lmax (truncated) or a workspace cap hit */
+
+int tsg_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Dense helper:  C[M,N] = A[rows,K] . Bt[K,N] (+ bias[N])      (fp32 MFMA, exact-fp32 fma chains)
+ * Replaces the one-off `nn.Linear`/`nn.Embedding`-product tables the engine pre-factors:
+ * road_emb.W_ih_l0^T, time_emb.W_ih_l0^T (function_g_fc.py:155-169) and node_emb.emb_fc^T
+ * (distance_gat_fc.py:129-131).  lda/ldb/ldc in elements.  K and N need not be tile multiples.
+ * ------------------------------------------------------------------------------------------ */
+int tsg_gemm_f32(const float* A, int lda, const float* Bt, int ldb, const float* bias, float* C, int ldc, int M,
+                 int N, int K, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * GAT road-graph encoder.  Replaces GATLayerImp3.forward + GATLayer.skip_concat_bias
+ * (generator/gat.py:138-200, :84-114) as called from DistanceGatFC._setup_node_emb /
+ * update_node_emb (generator/distance_gat_fc.py:189-223), eval mode, ELU activation.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct tsg_gat_desc {
+  int32_t n_nodes;     /* N */
+  int32_t n_edges;     /* E */
+  int32_t fin;         /* FIN  (input features per node) */
+  int32_t heads;       /* NH */
+  int32_t fout;        /* F per head */
+  int32_t concat;      /* 0: mean over heads (out is N x F), 1: concat (out is N x NH*F) */
+  int32_t skip_identity; /* 1 when FIN == F: skip adds x itself (gat.py:94-97) */
+  int32_t reserved;
+  const float* x;        /* [N][FIN] */
+  const float* w_proj_t; /* [FIN][NH*F]  = linear_proj.weight^T */
+  const float* w_skip_t; /* [FIN][NH*F]  = skip_proj.weight^T (ignored when skip_identity) */
+  const float* a_src;    /* [NH][F] scoring_fn_source */
+  const float* a_trg;    /* [NH][F] scoring_fn_target */
+  const float* bias;     /* [F] or [NH*F] (concat), may be NULL */
+  const int32_t* in_ptr; /* [N+1] CSR by TARGET node, edges kept in original COO order */
+  const int32_t* in_src; /* [E] source node of every incoming edge */
+  float* proj;           /* workspace [N][NH*F] */
+  float* s_src;          /* workspace [N][NH] */
+  float* s_trg;          /* workspace [N][NH] */
+  float* gmax;           /* workspace [1]: global max edge score (gat.py:221) */
+  float* out;            /* [N][F] or [N][NH*F] */
+  size_t proj_bytes, s_bytes, out_bytes;
+} tsg_gat_desc;
+
+int tsg_gat_forward(const tsg_gat_desc* d, void* stream);
+
+/* GAT input features: x[n] = [lon_embed[nf[n][-2]], lat_embed[nf[n][-1]], nf[n][:-2]]
+ * (generator/distance_gat_fc.py:191-197).  node_features [N][fraw] f32 (last two columns hold the
+ * integer lon/lat grid cells), lon_embed [n_lon][gps], lat_embed [n_lat][gps], x [N][2*gps + fraw - 2].
+ * Out-of-range grid cells set *err_flag (device int32) to 1 and read row 0. */
+int tsg_gat_build_input(const float* node_features, int n_nodes, int fraw, const float* lon_embed, int n_lon,
+                        const float* lat_embed, int n_lat, int gps_dim, float* x, int32_t* err_flag, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Model tables shared by the scoring entry points (function G + function H of
+ * generator/generator_v4.py:31-72, pre-factored on the host by ts-trajgen_amd/engine.py).
+ * Hp = hidden size padded to a multiple of 64 (padding units have zero weights).
+ * Gate columns are interleaved: col = (u/32)*128 + gate*32 + u%32, gates in torch order i,f,g,o.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct tsg_model {
+  int32_t n_roads;   /* rows of out_w / pfrom / pto */
+  int32_t n_time;    /* rows of tproj */
+  int32_t hp;        /* padded hidden size, multiple of 64, <= 512 */
+  int32_t n_layers;  /* LSTM layers, 1..TSG_MAX_LAYERS */
+  const float* xproj;                /* [n_roads+1][4Hp] road_emb . W_ih_l0[:, :Er]^T */
+  const float* tproj;                /* [n_time][4Hp]   time_emb . W_ih_l0[:, Er:]^T + b_ih_l0 + b_hh_l0 */
+  const float* whh0_t;               /* [Hp][4Hp]       W_hh_l0^T */
+  const float* wl_t[TSG_MAX_LAYERS]; /* l>=1: [2Hp][4Hp] = [W_ih_l^T ; W_hh_l^T]; entry 0 unused */
+  const float* bl[TSG_MAX_LAYERS];   /* l>=1: [4Hp] b_ih_l + b_hh_l; entry 0 unused */
+  const float* out_w;                /* [n_roads][Hp] function_g.out_fc.weight */
+  const float* out_b;                /* [n_roads] */
+  const float* pfrom;                /* [n_roads][10]  node_emb . emb_fc.weight[:, :F]^T */
+  const float* pto;                  /* [n_roads][10]  node_emb . emb_fc.weight[:, F:]^T + emb_fc.bias */
+  const float* hparams;              /* [42]: dis_fc.w[10], dis_fc.b[10], out_fc.w[20], out_fc.b, w1 */
+} tsg_model;
+
+/* ------------------------------------------------------------------------------------------
+ * One LSTM layer step for a batch of rows (the per-expansion recurrent cell).  Replaces the
+ * `nn.LSTM` call of function_g_fc.py:169, incrementally: row i continues from the state rows
+ * prev_idx[i] and writes state rows out_idx[i] (row indices into the [rows][Hp] state arrays;
+ * prev_idx < 0 = zero initial state).  n_rows_dev (device int) may be NULL -> n_rows_host.
+ * layer 0 adds xproj[rid[i]] + tproj[tcode[i]]; layer l>=1 reads h_below rows out_idx[i].
+ * ------------------------------------------------------------------------------------------ */
+typedef struct tsg_lstm_step {
+  int32_t layer;
+  int32_t n_rows_host;
+  const int32_t* n_rows_dev;
+  const int64_t* prev_idx; /* [n] */
+  const int64_t* out_idx;  /* [n] */
+  const int32_t* rid;      /* [n] (layer 0) */
+  const int32_t* tcode;    /* [n] (layer 0) */
+  const float* h_below;    /* [rows][Hp] (layer >= 1): new hidden of layer-1 */
+  float* h;                /* [rows][Hp] this layer's hidden states (read prev, write out) */
+  float* c;                /* [rows][Hp] this layer's cell states */
+  size_t state_rows;       /* rows in h / c, for bounds checking of host-known indices */
+} tsg_lstm_step;
+
+int tsg_lstm_step_batched(const tsg_model* m, const tsg_lstm_step* s, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Candidate scoring for explicit (prefix, candidates, distances) rows: the drop-in for
+ * GeneratorV4.predict (generator/generator_v4.py:56-72) == softmax((1-w1) softmax(G) + w1 softmax(H)).
+ * Row i attends over the top-layer hidden rows chain[chain_ptr[i] .. chain_ptr[i+1]) (last = query),
+ * scores candidates cand[cand_ptr[i] .. cand_ptr[i+1]) with distances dis[...] towards des[i] and
+ * writes prob[...] (and, if non-NULL, the separate G and H softmaxes).  <= TSG_MAX_DEGREE candidates.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct tsg_score_batch {
+  int32_t n_rows;
+  const int32_t* chain_ptr; /* [n_rows+1] */
+  const int64_t* chain;     /* state-row indices, oldest first */
+  const float* h_top;       /* [rows][Hp] top-layer hidden states */
+  const int32_t* cand_ptr;  /* [n_rows+1] */
+  const int32_t* cand;      /* candidate road ids */
+  const float* dis;         /* candidate distances (units of 100 m, search.py:355-356) */
+  const int32_t* des;       /* [n_rows] */
+  float* prob;              /* out, same layout as cand */
+  float* prob_g;            /* out or NULL */
+  float* prob_h;            /* out or NULL */
+} tsg_score_batch;
+
+int tsg_score_candidates(const tsg_model* m, const tsg_score_batch* b, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Batched A* engine.  Replaces Searcher.astar_search (search.py:240-424) and
+ * Searcher.astar_search_in_region (search.py:426-612) for MANY OD pairs at once; the call
+ * our_model_generate.py:417-426 makes one OD at a time.  `slots` searches are in flight; a
+ * finished slot pulls the next pending OD.  One superstep = frontier kernel (relax the previous
+ * expansion with heapq-exact ordering, pop the next node, goal/closed/region checks, time update
+ * search.py:376-384) -> LSTM layer kernels -> scoring kernel (attention over the ancestor chain,
+ * gathered out_fc rows, factored H, on-device WGS-84 geodesic, double softmax, log).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct tsg_graph {
+  int32_t n_roads;
+  int32_t max_degree;
+  const int32_t* indptr;  /* [n_roads+1] successors CSR, order of adjacent_list preserved */
+  const int32_t* indices; /* [E] */
+  const double* lonlat;   /* [n_roads][2] (lon, lat) degrees, road_center_gps */
+  const int32_t* cost;    /* [24][n_roads] seconds: rtd if != 1 else int(round(len/8.334)) (search.py:376-381) */
+  const int32_t* label;   /* [n_roads] region label per road, or NULL (no in-region gating) */
+} tsg_graph;
+
+typedef struct tsg_od_batch {
+  int32_t n_od;
+  int32_t lmax;                /* row length of out_rid / out_time */
+  const int32_t* prefix_ptr;   /* [n_od+1] */
+  const int32_t* prefix_rid;   /* known trajectory prefix (trace_loc), >= 1 element per OD */
+  const int32_t* prefix_time;  /* trace_tim */
+  const int32_t* des;          /* [n_od] */
+  const int32_t* default_len;  /* [n_od] */
+  const int32_t* max_step;     /* [n_od] */
+  const int32_t* allow_label;  /* [n_od] label the expansion is confined to, <0 = unrestricted; or NULL */
+  int32_t* out_rid;            /* [n_od][lmax] */
+  int32_t* out_time;           /* [n_od][lmax] */
+  int32_t* out_len;            /* [n_od] true length (may exceed lmax -> OVERFLOW bit) */
+  int32_t* out_status;         /* [n_od] TSG_STATUS_* */
+  int32_t* out_steps;          /* [n_od] expansions (`step`, search.py:420) */
+  int32_t poplog_cap;          /* entries per OD in the pop log, 0 = off */
+  int32_t* poplog_rid;         /* [n_od][poplog_cap] rid of every non-stale pop, in order */
+  float* poplog_prio;          /* [n_od][poplog_cap] its priority (-log_prob) */
+  int32_t* poplog_n;           /* [n_od] */
+} tsg_od_batch;
+
+typedef struct tsg_engine {
+  int32_t slots;     /* B: searches in flight */
+  int32_t exp_cap;   /* expanded nodes per slot  >= max prefix + max max_step */
+  int32_t node_cap;  /* discovered nodes per slot (<= 2^20 - 1) */
+  int32_t heap_cap;  /* heap entries per slot */
+  /* workspaces (caller-allocated); *_bytes are checked against the dims above */
+  int32_t* slot_state;  size_t slot_state_bytes;  /* [B][32] int32 */
+  uint64_t* heap;       size_t heap_bytes;        /* [B][heap_cap] {float prio; int32 node} */
+  uint32_t* table;      size_t table_bytes;       /* [B][n_roads] rid -> (generation<<20 | node+1), zeroed by caller */
+  int32_t* nodes;       size_t nodes_bytes;       /* [B][node_cap][8] int32 */
+  int32_t* exp_meta;    size_t exp_meta_bytes;    /* [B][exp_cap][4] {parent, rid, tcode, depth} */
+  float* h[TSG_MAX_LAYERS];                       /* [B*exp_cap][Hp] per layer */
+  float* c[TSG_MAX_LAYERS];
+  size_t state_bytes;                             /* bytes of EACH h[l] / c[l] */
+  int32_t* items;       size_t items_bytes;       /* [B][8] work items of the current superstep */
+  float* cand_lp;       size_t cand_lp_bytes;     /* [B][max_degree] */
+  int32_t* counters;    size_t counters_bytes;    /* [16]: 0,1 item counters (ping-pong), 2 next OD, 3 finished ODs,
+                                                     4 total expansions, 5 total model evaluations, 6 error flag */
+} tsg_engine;
+
+/* Reset slot states and counters for a new OD batch (enqueues memsets + an init kernel). */
+int tsg_engine_reset(const tsg_engine* e, const tsg_graph* g, void* stream);
+
+/* Enqueue `n_supersteps` supersteps.  `first_superstep` is the index of the first one (parity
+ * selects the ping-pong item counter).  Poll counters[3] == n_od for completion. */
+int tsg_engine_run(const tsg_model* m, const tsg_graph* g, const tsg_od_batch* od, const tsg_engine* e,
+                   int32_t first_superstep, int32_t n_supersteps, void* stream);
+
+/* The two kernels of one superstep, individually launchable (tests, profiling). */
+int tsg_frontier_expand_select(const tsg_graph* g, const tsg_od_batch* od, const tsg_engine* e, int32_t superstep,
+                               void* stream);
+int tsg_score_frontier(const tsg_model* m, const tsg_graph* g, const tsg_engine* e, int32_t superstep,
+                       void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TSG_H_ */

@@ -96,3 +96,21 @@ class GoldenRegionWorld(object):
                 'region_transfer_freq': self.meta['region_transfer_freq'],
                 'rid2region': self.meta['rid2region'], 'region2rid': self.meta['region2rid'],
                 'region_time_distribution': self.npz['region_time_distribution'].astype(int)}
+
+
+def build_generator(world, device):
+    """Our GeneratorV4 (HIP path) loaded with a golden world's weights, eval mode, on `device`."""
+    import torch
+    from ts_trajgen_amd.generator import GeneratorV4
+    cfg = json.loads(json.dumps(world.cfg))
+    cfg['function_g']['device'] = device
+    cfg['function_h']['device'] = device
+    model = GeneratorV4(config=cfg, data_feature=world.data_feature(torch))
+    model.function_g.load_state_dict({k: torch.as_tensor(v) for k, v in world.g_state.items()})
+    model.function_h.load_state_dict({k: torch.as_tensor(v) for k, v in world.h_state.items()})
+    with torch.no_grad():
+        model.w1.fill_(world.w1)
+    model = model.to(device)
+    model.function_h.node_features = model.function_h.node_features.to(device)
+    model.train(False)
+    return model

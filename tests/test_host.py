@@ -1,0 +1,87 @@
+"""CPU-only checks: substrate construction, the C-ABI library's exports, host-side layout helpers."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from tests._fixtures import GoldenRoadWorld
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_csr_bit_exact():
+    """G8: indices[indptr[r]:indptr[r+1]] == adjacent_list[str(r)] for every r."""
+    from ts_trajgen_amd.synth import csr_from_adjacent_list, street_grid_network, porto_scale_network
+    w = GoldenRoadWorld()
+    for adj, n in ((w.adjacent_list, w.n), (street_grid_network(8).adjacent_list, 112),
+                   (porto_scale_network().adjacent_list, 11095)):
+        indptr, indices = csr_from_adjacent_list(adj, n)
+        assert indptr.dtype == np.int32 and indices.dtype == np.int32
+        for r in range(n):
+            assert indices[indptr[r]:indptr[r + 1]].tolist() == list(adj.get(str(r), []))
+        assert indptr[-1] == sum(len(v) for v in adj.values())
+
+
+def test_library_exports_every_declared_symbol():
+    """libtsg.so loads and exports each function include/tsg.h declares (no compute call)."""
+    lib_path = os.path.join(ROOT, 'ts-trajgen_amd', 'csrc', 'libtsg.so')
+    if not os.path.exists(lib_path):
+        pytest.fail('libtsg.so is not built: run __graft_entry__.build()')
+    header = open(os.path.join(ROOT, 'include', 'tsg.h')).read()
+    declared = set(re.findall(r'^int (tsg_\w+)\(', header, flags=re.M))
+    assert len(declared) >= 10
+    lib = ctypes.CDLL(lib_path)
+    for name in declared:
+        assert hasattr(lib, name), name
+    from ts_trajgen_amd import _lib
+    assert set(_lib.EXPORTS) == declared
+    assert lib.tsg_version() == 1
+
+
+def test_struct_sizes_match_header():
+    """ctypes mirrors have the field counts/sizes the header implies (pointer = 8, int32 = 4)."""
+    from ts_trajgen_amd import _lib
+    assert ctypes.sizeof(_lib.Graph) == 8 + 5 * 8
+    assert ctypes.sizeof(_lib.Model) == 16 + (3 + 8 + 5) * 8
+    assert ctypes.sizeof(_lib.Engine) == 16 + 5 * 16 + 8 * 8 + 8 + 3 * 16
+
+
+def test_gate_permutation_roundtrip():
+    from ts_trajgen_amd.engine import gate_permutation
+    for hidden in (16, 32, 128, 256):
+        hp = (hidden + 63) // 64 * 64
+        src = gate_permutation(hidden, hp)
+        valid = src[src >= 0]
+        assert sorted(valid.tolist()) == list(range(4 * hidden))
+        # the four gates of unit u sit 32 columns apart inside one 128-column tile
+        for u in (0, hidden - 1):
+            cols = [int(np.flatnonzero(src == g * hidden + u)[0]) for g in range(4)]
+            assert [c - cols[0] for c in cols] == [0, 32, 64, 96] and cols[0] // 128 == u // 32
+
+
+def test_cost_table_matches_reference_expression():
+    """search.py:376-381 incl. Python's banker's rounding."""
+    from oracle.search import travel_cost
+    w = GoldenRoadWorld()
+    rtd = w.rtd.astype(int)
+    n = w.n
+    default = np.array([int(round(w.road_length[str(r)] / 8.334)) for r in range(n)])
+    cost = np.where(rtd != 1, rtd, default[None, :])
+    for hour in (0, 7, 23):
+        for rid in range(0, n, 37):
+            assert cost[hour, rid] == travel_cost(rtd, w.road_length, hour, rid)
+
+
+def test_host_geodesic_matches_oracle():
+    from oracle import geodesic
+    from ts_trajgen_amd import geo
+    rng = np.random.RandomState(0)
+    for _ in range(200):
+        a = (116.25 + rng.rand() * 0.3, 39.79 + rng.rand() * 0.3)
+        b = (116.25 + rng.rand() * 0.3, 39.79 + rng.rand() * 0.3)
+        assert abs(geodesic.candidate_dis(a, b) - geo.candidate_dis(a, [b])[0]) < 1e-9
+    assert geo.candidate_dis((116.3, 39.9), [(116.3, 39.9)])[0] == 0.0
+    # known value: one degree of latitude at the equator on WGS-84 is 110574.389 m
+    assert abs(geodesic.geodesic_m(0.0, 0.0, 1.0, 0.0) - 110574.389) < 1e-2

@@ -1,0 +1,121 @@
+"""ctypes binding of csrc/libtsg.so (the C ABI declared in include/tsg.h).
+
+There is deliberately no fallback: if the library is missing or a symbol is absent, importing a
+compute entry point raises.  Structures mirror include/tsg.h field for field.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libtsg.so')
+
+TSG_MAX_LAYERS = 4
+TSG_MAX_DEGREE = 64
+TSG_H_HIDDEN = 10
+STATUS_UNTOUCHED, STATUS_REACHED, STATUS_FALLBACK, STATUS_OVERFLOW = 0, 1, 2, 0x100
+
+EXPORTS = ('tsg_version', 'tsg_gemm_f32', 'tsg_gat_forward', 'tsg_gat_build_input', 'tsg_lstm_step_batched',
+           'tsg_score_candidates', 'tsg_engine_reset', 'tsg_engine_run', 'tsg_frontier_expand_select',
+           'tsg_score_frontier')
+
+_p = C.c_void_p
+_i32 = C.c_int32
+_sz = C.c_size_t
+
+
+class GatDesc(C.Structure):
+    _fields_ = [('n_nodes', _i32), ('n_edges', _i32), ('fin', _i32), ('heads', _i32), ('fout', _i32),
+                ('concat', _i32), ('skip_identity', _i32), ('reserved', _i32),
+                ('x', _p), ('w_proj_t', _p), ('w_skip_t', _p), ('a_src', _p), ('a_trg', _p), ('bias', _p),
+                ('in_ptr', _p), ('in_src', _p), ('proj', _p), ('s_src', _p), ('s_trg', _p), ('gmax', _p),
+                ('out', _p), ('proj_bytes', _sz), ('s_bytes', _sz), ('out_bytes', _sz)]
+
+
+class Model(C.Structure):
+    _fields_ = [('n_roads', _i32), ('n_time', _i32), ('hp', _i32), ('n_layers', _i32),
+                ('xproj', _p), ('tproj', _p), ('whh0_t', _p),
+                ('wl_t', _p * TSG_MAX_LAYERS), ('bl', _p * TSG_MAX_LAYERS),
+                ('out_w', _p), ('out_b', _p), ('pfrom', _p), ('pto', _p), ('hparams', _p)]
+
+
+class LstmStep(C.Structure):
+    _fields_ = [('layer', _i32), ('n_rows_host', _i32), ('n_rows_dev', _p), ('prev_idx', _p), ('out_idx', _p),
+                ('rid', _p), ('tcode', _p), ('h_below', _p), ('h', _p), ('c', _p), ('state_rows', _sz)]
+
+
+class ScoreBatch(C.Structure):
+    _fields_ = [('n_rows', _i32), ('chain_ptr', _p), ('chain', _p), ('h_top', _p), ('cand_ptr', _p),
+                ('cand', _p), ('dis', _p), ('des', _p), ('prob', _p), ('prob_g', _p), ('prob_h', _p)]
+
+
+class Graph(C.Structure):
+    _fields_ = [('n_roads', _i32), ('max_degree', _i32), ('indptr', _p), ('indices', _p), ('lonlat', _p),
+                ('cost', _p), ('label', _p)]
+
+
+class OdBatch(C.Structure):
+    _fields_ = [('n_od', _i32), ('lmax', _i32), ('prefix_ptr', _p), ('prefix_rid', _p), ('prefix_time', _p),
+                ('des', _p), ('default_len', _p), ('max_step', _p), ('allow_label', _p),
+                ('out_rid', _p), ('out_time', _p), ('out_len', _p), ('out_status', _p), ('out_steps', _p),
+                ('poplog_cap', _i32), ('poplog_rid', _p), ('poplog_prio', _p), ('poplog_n', _p)]
+
+
+class Engine(C.Structure):
+    _fields_ = [('slots', _i32), ('exp_cap', _i32), ('node_cap', _i32), ('heap_cap', _i32),
+                ('slot_state', _p), ('slot_state_bytes', _sz), ('heap', _p), ('heap_bytes', _sz),
+                ('table', _p), ('table_bytes', _sz), ('nodes', _p), ('nodes_bytes', _sz),
+                ('exp_meta', _p), ('exp_meta_bytes', _sz),
+                ('h', _p * TSG_MAX_LAYERS), ('c', _p * TSG_MAX_LAYERS), ('state_bytes', _sz),
+                ('items', _p), ('items_bytes', _sz), ('cand_lp', _p), ('cand_lp_bytes', _sz),
+                ('counters', _p), ('counters_bytes', _sz)]
+
+
+_lib = None
+
+
+def lib():
+    """Load libtsg.so once; raise loudly when it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError('libtsg.so is not built (%s). Run `python -c "import __graft_entry__ as g; g.build()"` '
+                           'or `make -C ts-trajgen_amd/csrc`. There is no CPU fallback.' % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    for name in EXPORTS:
+        if not hasattr(L, name):
+            raise RuntimeError('libtsg.so lacks symbol %s (stale build?)' % name)
+    L.tsg_version.restype = C.c_int
+    L.tsg_gemm_f32.argtypes = [_p, C.c_int, _p, C.c_int, _p, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p]
+    L.tsg_gat_forward.argtypes = [C.POINTER(GatDesc), _p]
+    L.tsg_gat_build_input.argtypes = [_p, C.c_int, C.c_int, _p, C.c_int, _p, C.c_int, C.c_int, _p, _p]
+    L.tsg_lstm_step_batched.argtypes = [C.POINTER(Model), C.POINTER(LstmStep), _p]
+    L.tsg_score_candidates.argtypes = [C.POINTER(Model), C.POINTER(ScoreBatch), _p]
+    L.tsg_engine_reset.argtypes = [C.POINTER(Engine), C.POINTER(Graph), _p]
+    L.tsg_engine_run.argtypes = [C.POINTER(Model), C.POINTER(Graph), C.POINTER(OdBatch), C.POINTER(Engine),
+                                 _i32, _i32, _p]
+    L.tsg_frontier_expand_select.argtypes = [C.POINTER(Graph), C.POINTER(OdBatch), C.POINTER(Engine), _i32, _p]
+    L.tsg_score_frontier.argtypes = [C.POINTER(Model), C.POINTER(Graph), C.POINTER(Engine), _i32, _p]
+    for name in EXPORTS:
+        getattr(L, name).restype = C.c_int
+    _lib = L
+    return L
+
+
+def check(rc, what):
+    if rc != 0:
+        names = {-1: 'TSG_E_INVALID', -2: 'TSG_E_TOO_SMALL', -3: 'TSG_E_LIMIT'}
+        msg = names.get(rc, 'hipError %d' % (-(rc + 1000)) if rc <= -1000 else str(rc))
+        raise RuntimeError('%s failed: %s' % (what, msg))
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None)."""
+    if t is None:
+        return None
+    return C.c_void_p(t.data_ptr())
+
+
+def current_stream():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,60 @@
+// Shared host/device helpers for libtsg (gfx950 only: wave64, MFMA f32 32x32x2).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/tsg.h"
+
+#define TSG_WAVE 64
+
+#define TSG_HIP_TRY(expr)                              \
+  do {                                                 \
+    hipError_t _e = (expr);                            \
+    if (_e != hipSuccess) return -(int)_e - 1000;      \
+  } while (0)
+
+#define TSG_LAUNCH_CHECK()                             \
+  do {                                                 \
+    hipError_t _e = hipGetLastError();                 \
+    if (_e != hipSuccess) return -(int)_e - 1000;      \
+  } while (0)
+
+static inline int tsg_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+typedef float tsg_f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ float tsg_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, TSG_WAVE);
+  return v;
+}
+
+__device__ __forceinline__ float tsg_wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, TSG_WAVE));
+  return v;
+}
+
+__device__ __forceinline__ float tsg_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// slot-state word indices (engine.slot_state is [B][32] int32)
+enum {
+  SS_PHASE = 0, SS_OD, SS_STEP, SS_HEAP_N, SS_NODE_N, SS_EXP_N, SS_GEN, SS_WOFF, SS_DES, SS_DEFLEN,
+  SS_MAXSTEP, SS_ALLOW, SS_WARM_K, SS_PLEN, SS_CUR_EXP, SS_CUR_RID, SS_CUR_C, SS_CUR_NEXT_TIME,
+  SS_CUR_LP, SS_BEST_LP, SS_BEST_PARENT, SS_BEST_RID, SS_BEST_TCODE, SS_HAVE_BEST, SS_NPOP, SS_POFF,
+  SS_CUR_DEPTH, SS_WORDS = 32
+};
+enum { PH_IDLE = 0, PH_WARMUP = 1, PH_SEARCH = 2, PH_EXPANDED = 3, PH_DONE = 4 };
+// counters
+enum { CT_ITEMS0 = 0, CT_ITEMS1 = 1, CT_NEXT_OD = 2, CT_FINISHED = 3, CT_EXPANSIONS = 4, CT_MODEL_EVALS = 5, CT_ERROR = 6 };
+// work item words ([B][8] int32)
+enum { IT_SLOT = 0, IT_EXP, IT_PARENT, IT_RID, IT_TCODE, IT_NCAND, IT_DES, IT_LP, IT_WORDS = 8 };
+// node record words ([B][node_cap][8] int32)
+enum { ND_RID = 0, ND_PARENT, ND_LP, ND_DATE_TIME, ND_EXP, ND_WORDS = 8 };
+enum { ND_OPEN = -1, ND_CLOSED_NOSLOT = -2 };
+// expanded-slot meta words ([B][exp_cap][4] int32)
+enum { EM_PARENT = 0, EM_RID, EM_TCODE, EM_DEPTH, EM_WORDS = 4 };
+
+#define TSG_GEN_SHIFT 20
+#define TSG_NODE_MASK ((1u << TSG_GEN_SHIFT) - 1u)
+#define TSG_GEN_MAX 4095

@@ -1,0 +1,283 @@
+// Dense contractions of the path on the gfx950 matrix cores (exact-fp32 v_mfma_f32_32x32x2_f32):
+//   * tsg_gemm_f32            one-off table products (road_emb.W_ih^T, node_emb.emb_fc^T, GAT projection)
+//   * tsg_lstm_step_batched   the per-expansion recurrent cell: gathered state rows x W^T + fused gate epilogue
+//
+// Tiling (both kernels): 256 threads = 4 waves; block tile 128 rows x 128 columns, BK = 32.
+// Wave w owns rows [32w, 32w+32) and all four 32-column sub-tiles -> 4 accumulators of 16 VGPRs.
+// For the LSTM the 128 columns of a tile are the 4 gates (i,f,g,o) of 32 hidden units (the host
+// interleaves the weight columns that way), so a lane holds all four gate pre-activations of one
+// (row, unit) in the same accumulator register index and the cell update needs no cross-lane traffic.
+// A tile in LDS as [row][33] (pad 1: conflict-free ds_read_b32 of 32 rows at fixed k),
+// B tile as [k][128] (lanes read consecutive columns).
+#include "tsg_common.h"
+
+#define BM 128
+#define BN 128
+#define BK 32
+#define A_LD 33
+
+struct TileLds {
+  float a[BM][A_LD];
+  float b[BK][BN];
+};
+
+__device__ __forceinline__ void mma_tile(const TileLds& t, int wave, int lane, tsg_f32x16 acc[4]) {
+  const int r = wave * 32 + (lane & 31);
+  const int kh = lane >> 5;
+#pragma unroll
+  for (int kk = 0; kk < BK; kk += 2) {
+    const float av = t.a[r][kk + kh];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float bv = t.b[kk + kh][g * 32 + (lane & 31)];
+      acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[g], 0, 0, 0);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------ plain GEMM
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A, int lda,
+                                                       const float* __restrict__ Bt, int ldb,
+                                                       const float* __restrict__ bias, float* __restrict__ C,
+                                                       int ldc, int M, int N, int K) {
+  __shared__ TileLds t;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int row0 = blockIdx.y * BM, col0 = blockIdx.x * BN;
+  tsg_f32x16 acc[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[g][i] = 0.0f;
+  for (int k0 = 0; k0 < K; k0 += BK) {
+    // A tile: 128 rows x 32 k
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int r = (tid >> 3) + 32 * p;
+      const int kc = (tid & 7) * 4;
+      const int gr = row0 + r;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int gk = k0 + kc + i;
+        t.a[r][kc + i] = (gr < M && gk < K) ? A[(size_t)gr * lda + gk] : 0.0f;
+      }
+    }
+    // B tile: 32 k x 128 cols
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int kr = (tid >> 5) + 8 * p;
+      const int cc = (tid & 31) * 4;
+      const int gk = k0 + kr;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int gc = col0 + cc + i;
+        t.b[kr][cc + i] = (gk < K && gc < N) ? Bt[(size_t)gk * ldb + gc] : 0.0f;
+      }
+    }
+    __syncthreads();
+    mma_tile(t, wave, lane, acc);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int gc = col0 + g * 32 + (lane & 31);
+    if (gc >= N) continue;
+    const float bv = bias ? bias[gc] : 0.0f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int gr = row0 + wave * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+      if (gr < M) C[(size_t)gr * ldc + gc] = acc[g][i] + bv;
+    }
+  }
+}
+
+extern "C" int tsg_gemm_f32(const float* A, int lda, const float* Bt, int ldb, const float* bias, float* C, int ldc,
+                            int M, int N, int K, void* stream) {
+  if (!A || !Bt || !C || M < 0 || N <= 0 || K <= 0 || lda < K || ldb < N || ldc < N) return TSG_E_INVALID;
+  if (M == 0) return 0;
+  dim3 grid(tsg_cdiv(N, BN), tsg_cdiv(M, BM));
+  if (grid.y > 65535u) return TSG_E_LIMIT;
+  hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(256), 0, (hipStream_t)stream, A, lda, Bt, ldb, bias, C, ldc, M, N, K);
+  TSG_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------ LSTM layer step
+struct LstmArgs {
+  int layer;
+  int hp;
+  int n_rows_host;
+  const int32_t* n_rows_dev;
+  // row addressing: either explicit index arrays (tsg_lstm_step_batched) or engine work items
+  const int64_t* prev_idx;
+  const int64_t* out_idx;
+  const int32_t* rid;
+  const int32_t* tcode;
+  const int32_t* items;  // engine mode when non-null: [n][IT_WORDS]
+  int exp_cap;           // engine mode: state row = slot * exp_cap + exp
+  const float* h_below;
+  float* h;
+  float* c;
+  const float* wt;     // [K][4Hp]
+  const float* xproj;  // layer 0
+  const float* tproj;  // layer 0
+  const float* bias;   // layer >= 1
+};
+
+__global__ __launch_bounds__(256) void lstm_layer_kernel(LstmArgs a) {
+  __shared__ TileLds t;
+  __shared__ long long s_prev[BM];
+  __shared__ long long s_out[BM];
+  __shared__ int s_rid[BM];
+  __shared__ int s_tc[BM];
+  const int n = a.n_rows_dev ? *a.n_rows_dev : a.n_rows_host;
+  const int hp = a.hp;
+  const int ct_n = hp / 32;  // column tiles (32 hidden units each)
+  // XCD-aware decode: the ct_n column tiles of one row tile share bid % 8 (one XCD's L2 serves the A rows)
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, within = bid >> 3;
+  const int rowtile = (within / ct_n) * 8 + xcd;
+  const int coltile = within % ct_n;
+  const int row0 = rowtile * BM;
+  if (row0 >= n) return;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  if (tid < BM) {
+    const int m = row0 + tid;
+    long long pv = -1, ov = -1;
+    int rd = 0, tc = 0;
+    if (m < n) {
+      if (a.items) {
+        const int32_t* it = a.items + (size_t)m * IT_WORDS;
+        const long long base = (long long)it[IT_SLOT] * a.exp_cap;
+        pv = it[IT_PARENT] >= 0 ? base + it[IT_PARENT] : -1;
+        ov = base + it[IT_EXP];
+        rd = it[IT_RID];
+        tc = it[IT_TCODE];
+      } else {
+        pv = a.prev_idx[m];
+        ov = a.out_idx[m];
+        if (a.layer == 0) {
+          rd = a.rid[m];
+          tc = a.tcode[m];
+        }
+      }
+    }
+    s_prev[tid] = pv;
+    s_out[tid] = ov;
+    s_rid[tid] = rd;
+    s_tc[tid] = tc;
+  }
+  __syncthreads();
+  tsg_f32x16 acc[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[g][i] = 0.0f;
+  const int K = a.layer == 0 ? hp : 2 * hp;
+  const int ldw = 4 * hp;
+  for (int k0 = 0; k0 < K; k0 += BK) {
+    const bool below = (a.layer > 0) && (k0 < hp);
+    const int kcol = below ? k0 : (a.layer > 0 ? k0 - hp : k0);
+    const float* src = below ? a.h_below : a.h;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int r = (tid >> 3) + 32 * p;
+      const int kc = (tid & 7) * 4;
+      const long long ridx = below ? s_out[r] : s_prev[r];
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ridx >= 0) v = *reinterpret_cast<const float4*>(src + (size_t)ridx * hp + kcol + kc);
+      t.a[r][kc + 0] = v.x;
+      t.a[r][kc + 1] = v.y;
+      t.a[r][kc + 2] = v.z;
+      t.a[r][kc + 3] = v.w;
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int kr = (tid >> 5) + 8 * p;
+      const int cc = (tid & 31) * 4;
+      const float4 v = *reinterpret_cast<const float4*>(a.wt + (size_t)(k0 + kr) * ldw + coltile * BN + cc);
+      *reinterpret_cast<float4*>(&t.b[kr][cc]) = v;
+    }
+    __syncthreads();
+    mma_tile(t, wave, lane, acc);
+    __syncthreads();
+  }
+  // fused cell update: lane holds i,f,g,o of (row, unit) in acc[0..3][i]
+  const int u = coltile * 32 + (lane & 31);
+  const int gcol = coltile * BN + (lane & 31);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int r = wave * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+    if (row0 + r >= n) continue;
+    float add[4];
+    if (a.layer == 0) {
+      const float* xp = a.xproj + (size_t)s_rid[r] * ldw + gcol;
+      const float* tp = a.tproj + (size_t)s_tc[r] * ldw + gcol;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) add[g] = xp[g * 32] + tp[g * 32];
+    } else {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) add[g] = a.bias[gcol + g * 32];
+    }
+    const float zi = acc[0][i] + add[0];
+    const float zf = acc[1][i] + add[1];
+    const float zg = acc[2][i] + add[2];
+    const float zo = acc[3][i] + add[3];
+    const long long pv = s_prev[r];
+    const float cp = pv >= 0 ? a.c[(size_t)pv * hp + u] : 0.0f;
+    const float cn = tsg_sigmoid(zf) * cp + tsg_sigmoid(zi) * tanhf(zg);
+    const float hn = tsg_sigmoid(zo) * tanhf(cn);
+    const size_t o = (size_t)s_out[r] * hp + u;
+    a.c[o] = cn;
+    a.h[o] = hn;
+  }
+}
+
+static int check_model_dims(const tsg_model* m) {
+  if (!m) return TSG_E_INVALID;
+  if (m->hp <= 0 || (m->hp % 64) != 0 || m->hp > 512) return TSG_E_INVALID;
+  if (m->n_layers < 1 || m->n_layers > TSG_MAX_LAYERS) return TSG_E_INVALID;
+  return 0;
+}
+
+int tsg_launch_lstm_layer(const tsg_model* m, int layer, int max_rows, const int32_t* n_rows_dev, int n_rows_host,
+                          const int64_t* prev_idx, const int64_t* out_idx, const int32_t* rid, const int32_t* tcode,
+                          const int32_t* items, int exp_cap, const float* h_below, float* h, float* c,
+                          hipStream_t stream) {
+  LstmArgs a;
+  a.layer = layer;
+  a.hp = m->hp;
+  a.n_rows_host = n_rows_host;
+  a.n_rows_dev = n_rows_dev;
+  a.prev_idx = prev_idx;
+  a.out_idx = out_idx;
+  a.rid = rid;
+  a.tcode = tcode;
+  a.items = items;
+  a.exp_cap = exp_cap;
+  a.h_below = h_below;
+  a.h = h;
+  a.c = c;
+  a.wt = layer == 0 ? m->whh0_t : m->wl_t[layer];
+  a.xproj = m->xproj;
+  a.tproj = m->tproj;
+  a.bias = layer == 0 ? nullptr : m->bl[layer];
+  if (!a.wt || !h || !c) return TSG_E_INVALID;
+  if (layer == 0 && (!m->xproj || !m->tproj)) return TSG_E_INVALID;
+  if (layer > 0 && (!a.bias || !h_below)) return TSG_E_INVALID;
+  if (max_rows <= 0) return 0;
+  const int rowtiles = tsg_cdiv(max_rows, BM);
+  const int grid = 8 * tsg_cdiv(rowtiles, 8) * (m->hp / 32);
+  hipLaunchKernelGGL(lstm_layer_kernel, dim3(grid), dim3(256), 0, stream, a);
+  TSG_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int tsg_lstm_step_batched(const tsg_model* m, const tsg_lstm_step* s, void* stream) {
+  int rc = check_model_dims(m);
+  if (rc) return rc;
+  if (!s || s->layer < 0 || s->layer >= m->n_layers || s->n_rows_host < 0) return TSG_E_INVALID;
+  if (!s->prev_idx || !s->out_idx) return TSG_E_INVALID;
+  if (s->layer == 0 && (!s->rid || !s->tcode)) return TSG_E_INVALID;
+  return tsg_launch_lstm_layer(m, s->layer, s->n_rows_host, s->n_rows_dev, s->n_rows_host, s->prev_idx, s->out_idx,
+                               s->rid, s->tcode, nullptr, 0, s->h_below, s->h, s->c, (hipStream_t)stream);
+}

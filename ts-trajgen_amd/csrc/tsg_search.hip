@@ -1,0 +1,583 @@
+// Batched A* engine kernels: candidate scoring (one wave64 per expanded node) and the per-OD
+// frontier kernel (heapq-exact priority queue, closed set, relax rules of search.py:385-419).
+#include "tsg_device.h"
+
+int tsg_launch_lstm_layer(const tsg_model* m, int layer, int max_rows, const int32_t* n_rows_dev, int n_rows_host,
+                          const int64_t* prev_idx, const int64_t* out_idx, const int32_t* rid, const int32_t* tcode,
+                          const int32_t* items, int exp_cap, const float* h_below, float* h, float* c,
+                          hipStream_t stream);
+
+// =====================================================================================
+// explicit-row scoring: GeneratorV4.predict (generator_v4.py:56-72) for (prefix, candidates, dis) rows
+// =====================================================================================
+__global__ __launch_bounds__(256) void score_batch_kernel(tsg_model m, tsg_score_batch sb) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= sb.n_rows) return;
+  const int hp = m.hp, J = hp / 64;
+  const int c0 = sb.chain_ptr[row], c1 = sb.chain_ptr[row + 1];
+  const int k0 = sb.cand_ptr[row], ncand = sb.cand_ptr[row + 1] - k0;
+  if (c1 <= c0 || ncand <= 0) return;
+  float q[TSG_MAXJ], key[TSG_MAXJ];
+  const float* qrow = sb.h_top + (size_t)sb.chain[c1 - 1] * hp;
+#pragma unroll
+  for (int j = 0; j < TSG_MAXJ; ++j) q[j] = (j < J) ? qrow[lane + 64 * j] : 0.0f;
+  AttnAcc acc;
+  attn_init(acc);
+  for (int i = c1 - 1; i >= c0; --i) {
+    const float* kr = sb.h_top + (size_t)sb.chain[i] * hp;
+#pragma unroll
+    for (int j = 0; j < TSG_MAXJ; ++j) key[j] = (j < J) ? kr[lane + 64 * j] : 0.0f;
+    attn_fold(acc, key, q, J);
+  }
+  float pooled[TSG_MAXJ];
+  const float inv = 1.0f / acc.l;
+#pragma unroll
+  for (int j = 0; j < TSG_MAXJ; ++j) pooled[j] = acc.v[j] * inv;
+  const int my_cand = lane < ncand ? sb.cand[k0 + lane] : 0;
+  const float my_dis = lane < ncand ? sb.dis[k0 + lane] : 0.0f;
+  float pg, ph;
+  const float f = score_row(m, pooled, J, lane, ncand, my_cand, my_dis, sb.des[row], &pg, &ph);
+  if (lane < ncand) {
+    sb.prob[k0 + lane] = f;
+    if (sb.prob_g) sb.prob_g[k0 + lane] = pg;
+    if (sb.prob_h) sb.prob_h[k0 + lane] = ph;
+  }
+}
+
+extern "C" int tsg_score_candidates(const tsg_model* m, const tsg_score_batch* b, void* stream) {
+  if (!m || !b) return TSG_E_INVALID;
+  if (m->hp <= 0 || (m->hp % 64) != 0 || m->hp > 512) return TSG_E_INVALID;
+  if (b->n_rows < 0 || !b->chain_ptr || !b->chain || !b->h_top || !b->cand_ptr || !b->cand || !b->dis || !b->des ||
+      !b->prob)
+    return TSG_E_INVALID;
+  if (!m->out_w || !m->out_b || !m->pfrom || !m->pto || !m->hparams) return TSG_E_INVALID;
+  if (b->n_rows == 0) return 0;
+  hipLaunchKernelGGL(score_batch_kernel, dim3(tsg_cdiv(b->n_rows, 4)), dim3(256), 0, (hipStream_t)stream, *m, *b);
+  TSG_LAUNCH_CHECK();
+  return 0;
+}
+
+// =====================================================================================
+// engine scoring: one wave per work item of the current superstep
+// =====================================================================================
+struct EngineDev {
+  tsg_engine e;
+  tsg_graph g;
+  tsg_od_batch od;
+};
+
+__global__ __launch_bounds__(256) void score_frontier_kernel(tsg_model m, EngineDev D, int superstep) {
+  const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  int32_t* counters = D.e.counters;
+  if (blockIdx.x == 0 && threadIdx.x == 0) counters[(superstep + 1) & 1] = 0;  // next superstep's item counter
+  const int n_items = counters[superstep & 1];
+  if (idx >= n_items) return;
+  const int32_t* it = D.e.items + (size_t)idx * IT_WORDS;
+  const int ncand = it[IT_NCAND];
+  if (ncand < 2) return;  // warm-up rows and single-successor expansions need no model call (search.py:302)
+  const int b = it[IT_SLOT], e = it[IT_EXP], rid = it[IT_RID], des = it[IT_DES];
+  const float lp_parent = __int_as_float(it[IT_LP]);
+  const int hp = m.hp, J = hp / 64;
+  const float* htop = D.e.h[m.n_layers - 1] + (size_t)b * D.e.exp_cap * hp;
+  const int32_t* em = D.e.exp_meta + (size_t)b * D.e.exp_cap * EM_WORDS;
+  float q[TSG_MAXJ], key[TSG_MAXJ];
+#pragma unroll
+  for (int j = 0; j < TSG_MAXJ; ++j) q[j] = (j < J) ? htop[(size_t)e * hp + lane + 64 * j] : 0.0f;
+  AttnAcc acc;
+  attn_init(acc);
+  int cur = e;
+  while (cur >= 0) {  // ancestor chain: parent pointers of closed (immutable) nodes
+    const int nxt = em[(size_t)cur * EM_WORDS + EM_PARENT];
+    const float* kr = htop + (size_t)cur * hp;
+#pragma unroll
+    for (int j = 0; j < TSG_MAXJ; ++j) key[j] = (j < J) ? kr[lane + 64 * j] : 0.0f;
+    attn_fold(acc, key, q, J);
+    cur = nxt;
+  }
+  float pooled[TSG_MAXJ];
+  const float inv = 1.0f / acc.l;
+#pragma unroll
+  for (int j = 0; j < TSG_MAXJ; ++j) pooled[j] = acc.v[j] * inv;
+  int my_cand = 0;
+  float my_dis = 0.0f;
+  if (lane < ncand) {
+    my_cand = D.g.indices[D.g.indptr[rid] + lane];
+    const double dlon = D.g.lonlat[2 * (size_t)des], dlat = D.g.lonlat[2 * (size_t)des + 1];
+    const double clon = D.g.lonlat[2 * (size_t)my_cand], clat = D.g.lonlat[2 * (size_t)my_cand + 1];
+    my_dis = (float)(tsg_dev_geodesic_m(dlat, dlon, clat, clon) / 1000.0 * 10.0);  // search.py:355-356
+  }
+  const float f = score_row(m, pooled, J, lane, ncand, my_cand, my_dis, des, nullptr, nullptr);
+  if (lane < ncand) D.e.cand_lp[(size_t)b * D.g.max_degree + lane] = logf(f) + lp_parent;  // search.py:370-373
+  if (lane == 0) atomicAdd(&counters[CT_MODEL_EVALS], 1);
+}
+
+// =====================================================================================
+// frontier kernel: one thread per in-flight search
+// =====================================================================================
+struct HeapEnt {
+  float prio;
+  int node;
+};
+
+__device__ __forceinline__ HeapEnt heap_ld(const uint64_t* h, int i) {
+  const uint64_t v = h[i];
+  HeapEnt e;
+  e.prio = __uint_as_float((uint32_t)v);
+  e.node = (int)(v >> 32);
+  return e;
+}
+__device__ __forceinline__ void heap_st(uint64_t* h, int i, HeapEnt e) {
+  h[i] = (uint64_t)__float_as_uint(e.prio) | ((uint64_t)(uint32_t)e.node << 32);
+}
+// (priority, SearchNode) tuple order of queue.PriorityQueue: priority, then SearchNode.__lt__ on the
+// node's CURRENT log_prob (search.py:48-52); the same node never compares less than itself.
+__device__ __forceinline__ bool ent_less(HeapEnt a, HeapEnt b, const int32_t* nodes) {
+  if (a.prio != b.prio) return a.prio < b.prio;
+  if (a.node == b.node) return false;
+  return __int_as_float(nodes[(size_t)a.node * ND_WORDS + ND_LP]) <
+         __int_as_float(nodes[(size_t)b.node * ND_WORDS + ND_LP]);
+}
+// heapq.heappush == append + _siftdown(heap, 0, len-1)
+__device__ __forceinline__ void heap_push(uint64_t* h, int& n, HeapEnt item, const int32_t* nodes) {
+  int pos = n++;
+  while (pos > 0) {
+    const int pp = (pos - 1) >> 1;
+    const HeapEnt par = heap_ld(h, pp);
+    if (!ent_less(item, par, nodes)) break;
+    heap_st(h, pos, par);
+    pos = pp;
+  }
+  heap_st(h, pos, item);
+}
+// heapq.heappop == pop last, put it at the root, _siftup (bubble smaller child up to a leaf, then _siftdown)
+__device__ __forceinline__ HeapEnt heap_pop(uint64_t* h, int& n, const int32_t* nodes) {
+  const HeapEnt last = heap_ld(h, n - 1);
+  --n;
+  if (n == 0) return last;
+  const HeapEnt ret = heap_ld(h, 0);
+  int pos = 0, child = 1;
+  while (child < n) {
+    const int right = child + 1;
+    HeapEnt ce = heap_ld(h, child);
+    if (right < n) {
+      const HeapEnt re = heap_ld(h, right);
+      if (!ent_less(ce, re, nodes)) {
+        child = right;
+        ce = re;
+      }
+    }
+    heap_st(h, pos, ce);
+    pos = child;
+    child = 2 * pos + 1;
+  }
+  while (pos > 0) {
+    const int pp = (pos - 1) >> 1;
+    const HeapEnt par = heap_ld(h, pp);
+    if (!ent_less(last, par, nodes)) break;
+    heap_st(h, pos, par);
+    pos = pp;
+  }
+  heap_st(h, pos, last);
+  return ret;
+}
+
+__global__ __launch_bounds__(64) void frontier_kernel(EngineDev D, int superstep) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= D.e.slots) return;
+  int32_t* S = D.e.slot_state + (size_t)b * SS_WORDS;
+  int phase = S[SS_PHASE];
+  if (phase == PH_DONE) return;
+  const tsg_graph& g = D.g;
+  const tsg_od_batch& od = D.od;
+  int32_t* counters = D.e.counters;
+  int32_t* item_cnt = &counters[superstep & 1];
+  uint64_t* heap = D.e.heap + (size_t)b * D.e.heap_cap;
+  uint32_t* table = D.e.table + (size_t)b * g.n_roads;
+  int32_t* nodes = D.e.nodes + (size_t)b * D.e.node_cap * ND_WORDS;
+  int32_t* em = D.e.exp_meta + (size_t)b * D.e.exp_cap * EM_WORDS;
+
+  int odi = S[SS_OD], step = S[SS_STEP], heap_n = S[SS_HEAP_N], node_n = S[SS_NODE_N], exp_n = S[SS_EXP_N];
+  int gen = S[SS_GEN], woff = S[SS_WOFF], des = S[SS_DES], deflen = S[SS_DEFLEN], max_step = S[SS_MAXSTEP];
+  int allow = S[SS_ALLOW], warm_k = S[SS_WARM_K], plen = S[SS_PLEN], poff = S[SS_POFF];
+  float best_lp = __int_as_float(S[SS_BEST_LP]);
+  int best_parent = S[SS_BEST_PARENT], best_rid = S[SS_BEST_RID], best_tcode = S[SS_BEST_TCODE];
+  int have_best = S[SS_HAVE_BEST], npop = S[SS_NPOP];
+  int err = 0;
+
+  // ---- relax the expansion scored during the previous superstep (search.py:385-419 / 317-350)
+  if (phase == PH_EXPANDED) {
+    const int e = S[SS_CUR_EXP], C = S[SS_CUR_C], rid = S[SS_CUR_RID], next_time = S[SS_CUR_NEXT_TIME];
+    const float lp_parent = __int_as_float(S[SS_CUR_LP]);
+    const int child_depth = S[SS_CUR_DEPTH] + 1;
+    const int tcode_child = next_time / 60 + woff;
+    const int base = g.indptr[rid];
+    for (int i = 0; i < C; ++i) {
+      const int c = g.indices[base + i];
+      const float lp = (C == 1) ? lp_parent : D.e.cand_lp[(size_t)b * g.max_degree + i];
+      const uint32_t t = table[c];
+      bool pushed = false;
+      int idx = -1;
+      if ((int)(t >> TSG_GEN_SHIFT) != gen) {  // c not in rid2node and not in close_set
+        if (node_n >= D.e.node_cap || heap_n >= D.e.heap_cap) {
+          err = 1;
+          break;
+        }
+        idx = node_n++;
+        int32_t* nd = nodes + (size_t)idx * ND_WORDS;
+        nd[ND_RID] = c;
+        nd[ND_PARENT] = e;
+        nd[ND_LP] = __float_as_int(lp);
+        nd[ND_DATE_TIME] = next_time;
+        nd[ND_EXP] = ND_OPEN;
+        table[c] = ((uint32_t)gen << TSG_GEN_SHIFT) | (uint32_t)idx;
+        pushed = true;
+      } else {
+        idx = (int)(t & TSG_NODE_MASK);
+        int32_t* nd = nodes + (size_t)idx * ND_WORDS;
+        if (nd[ND_EXP] == ND_OPEN && __int_as_float(nd[ND_LP]) < lp) {  // c in rid2node, strictly better
+          if (heap_n >= D.e.heap_cap) {
+            err = 1;
+            break;
+          }
+          nd[ND_PARENT] = e;
+          nd[ND_LP] = __float_as_int(lp);
+          nd[ND_DATE_TIME] = next_time;
+          pushed = true;
+        }
+      }
+      if (pushed) {
+        HeapEnt he;
+        he.prio = -lp;
+        he.node = idx;
+        heap_push(heap, heap_n, he, nodes);
+        // default-length fallback snapshot (search.py:397-402): np.exp(lp) > best_score, best_score starts at 0
+        if (child_depth == deflen && lp > best_lp && lp > -745.13f) {
+          best_lp = lp;
+          best_parent = e;
+          best_rid = c;
+          best_tcode = tcode_child;
+          have_best = 1;
+        }
+      }
+    }
+    phase = PH_SEARCH;
+  }
+
+  bool emitted = false;
+  while (!emitted && !err) {
+    if (phase == PH_IDLE) {
+      if (gen >= TSG_GEN_MAX) {  // table generation space exhausted for this slot: stop refilling it
+        phase = PH_DONE;
+        break;
+      }
+      odi = atomicAdd(&counters[CT_NEXT_OD], 1);
+      if (odi >= od.n_od) {
+        phase = PH_DONE;
+        break;
+      }
+      // ---- start a new search (search.py:255-278)
+      ++gen;
+      poff = od.prefix_ptr[odi];
+      plen = od.prefix_ptr[odi + 1] - poff;
+      des = od.des[odi];
+      deflen = od.default_len[odi];
+      max_step = od.max_step[odi];
+      allow = od.allow_label ? od.allow_label[odi] : -1;
+      const int start_time = od.prefix_time[poff + plen - 1];
+      woff = start_time >= 1440 ? 1440 : 0;
+      if (plen - 1 + max_step > D.e.exp_cap) max_step = D.e.exp_cap - (plen - 1);  // never hit: host sizes exp_cap
+      for (int k = 0; k + 1 < plen; ++k) {
+        em[(size_t)k * EM_WORDS + EM_PARENT] = k - 1;
+        em[(size_t)k * EM_WORDS + EM_RID] = od.prefix_rid[poff + k];
+        em[(size_t)k * EM_WORDS + EM_TCODE] = od.prefix_time[poff + k];
+        em[(size_t)k * EM_WORDS + EM_DEPTH] = k + 1;
+      }
+      const int r0 = od.prefix_rid[poff + plen - 1];
+      nodes[ND_RID] = r0;
+      nodes[ND_PARENT] = plen - 2;
+      nodes[ND_LP] = __float_as_int(0.0f);
+      nodes[ND_DATE_TIME] = (start_time - woff) * 60;
+      nodes[ND_EXP] = ND_OPEN;
+      table[r0] = ((uint32_t)gen << TSG_GEN_SHIFT) | 0u;
+      HeapEnt he;
+      he.prio = 0.0f;
+      he.node = 0;
+      heap_st(heap, 0, he);
+      heap_n = 1;
+      node_n = 1;
+      exp_n = plen - 1;
+      step = 0;
+      have_best = 0;
+      best_lp = -INFINITY;
+      best_parent = -1;
+      best_rid = -1;
+      best_tcode = 0;
+      npop = 0;
+      warm_k = 0;
+      phase = plen > 1 ? PH_WARMUP : PH_SEARCH;
+    }
+    if (phase == PH_WARMUP) {  // run the recurrent cell over the known prefix, one element per superstep
+      const int k = warm_k++;
+      const int slot = atomicAdd(item_cnt, 1);
+      int32_t* it = D.e.items + (size_t)slot * IT_WORDS;
+      it[IT_SLOT] = b;
+      it[IT_EXP] = k;
+      it[IT_PARENT] = k - 1;
+      it[IT_RID] = od.prefix_rid[poff + k];
+      it[IT_TCODE] = od.prefix_time[poff + k];
+      it[IT_NCAND] = 0;
+      it[IT_DES] = des;
+      it[IT_LP] = 0;
+      if (warm_k >= plen - 1) phase = PH_SEARCH;
+      emitted = true;
+      break;
+    }
+    // ---- PH_SEARCH: pop until a node can be expanded (search.py:279-300)
+    int fin_status = -1, fin_parent = -1, fin_rid = -1, fin_tcode = 0, fin_depth = 0;
+    while (heap_n > 0 && step < max_step) {
+      const HeapEnt top = heap_pop(heap, heap_n, nodes);
+      int32_t* nd = nodes + (size_t)top.node * ND_WORDS;
+      if (nd[ND_EXP] != ND_OPEN) continue;  // stale duplicate of a closed rid (search.py:284-287)
+      const int rid = nd[ND_RID];
+      const int parent = nd[ND_PARENT];
+      const int date_time = nd[ND_DATE_TIME];
+      const int depth = (parent >= 0 ? em[(size_t)parent * EM_WORDS + EM_DEPTH] : 0) + 1;
+      const int tcode = date_time / 60 + woff;
+      if (od.poplog_cap > 0 && npop < od.poplog_cap) {
+        od.poplog_rid[(size_t)odi * od.poplog_cap + npop] = rid;
+        od.poplog_prio[(size_t)odi * od.poplog_cap + npop] = top.prio;
+      }
+      ++npop;
+      if (rid == des) {  // search.py:291-297
+        nd[ND_EXP] = ND_CLOSED_NOSLOT;
+        fin_status = TSG_STATUS_REACHED;
+        fin_parent = parent;
+        fin_rid = rid;
+        fin_tcode = tcode;
+        fin_depth = depth;
+        break;
+      }
+      const int beg = g.indptr[rid];
+      const int C = g.indptr[rid + 1] - beg;
+      const bool gate = C > 0 && (allow < 0 || (g.label && g.label[rid] == allow));  // search.py:300 / :487
+      ++step;  // search.py:420
+      if (!gate) {
+        nd[ND_EXP] = ND_CLOSED_NOSLOT;
+        continue;
+      }
+      if (exp_n >= D.e.exp_cap) {
+        err = 1;
+        break;
+      }
+      const int e = exp_n++;
+      nd[ND_EXP] = e;
+      em[(size_t)e * EM_WORDS + EM_PARENT] = parent;
+      em[(size_t)e * EM_WORDS + EM_RID] = rid;
+      em[(size_t)e * EM_WORDS + EM_TCODE] = tcode;
+      em[(size_t)e * EM_WORDS + EM_DEPTH] = depth;
+      const int hour = date_time / 3600;                                   // search.py:376
+      const int cost = g.cost[(size_t)hour * g.n_roads + rid];              // search.py:377-381 (pre-resolved)
+      const int next_time = (date_time + cost) % 86400;                     // search.py:382
+      S[SS_CUR_EXP] = e;
+      S[SS_CUR_RID] = rid;
+      S[SS_CUR_C] = C;
+      S[SS_CUR_NEXT_TIME] = next_time;
+      S[SS_CUR_LP] = nd[ND_LP];
+      S[SS_CUR_DEPTH] = depth;
+      const int slot = atomicAdd(item_cnt, 1);
+      int32_t* it = D.e.items + (size_t)slot * IT_WORDS;
+      it[IT_SLOT] = b;
+      it[IT_EXP] = e;
+      it[IT_PARENT] = parent;
+      it[IT_RID] = rid;
+      it[IT_TCODE] = tcode;
+      it[IT_NCAND] = C;
+      it[IT_DES] = des;
+      it[IT_LP] = nd[ND_LP];
+      phase = PH_EXPANDED;
+      emitted = true;
+      break;
+    }
+    if (emitted || err) break;
+    // ---- the search is over (search.py:421-424): destination popped, queue empty, or budget spent
+    if (fin_status < 0) {
+      if (have_best) {
+        fin_status = TSG_STATUS_FALLBACK;
+        fin_parent = best_parent;
+        fin_rid = best_rid;
+        fin_tcode = best_tcode;
+        fin_depth = deflen;
+      } else {
+        fin_status = TSG_STATUS_UNTOUCHED;
+        fin_parent = plen - 2;
+        fin_rid = od.prefix_rid[poff + plen - 1];
+        fin_tcode = od.prefix_time[poff + plen - 1];
+        fin_depth = plen;
+      }
+    }
+    {
+      const int lmax = od.lmax;
+      if (fin_depth > lmax) fin_status |= TSG_STATUS_OVERFLOW;
+      int32_t* orid = od.out_rid + (size_t)odi * lmax;
+      int32_t* otim = od.out_time + (size_t)odi * lmax;
+      int i = fin_depth - 1;
+      if (i < lmax) {
+        orid[i] = fin_rid;
+        otim[i] = fin_tcode;
+      }
+      int cur = fin_parent;
+      --i;
+      while (cur >= 0 && i >= 0) {
+        if (i < lmax) {
+          orid[i] = em[(size_t)cur * EM_WORDS + EM_RID];
+          otim[i] = em[(size_t)cur * EM_WORDS + EM_TCODE];
+        }
+        cur = em[(size_t)cur * EM_WORDS + EM_PARENT];
+        --i;
+      }
+      od.out_len[odi] = fin_depth;
+      od.out_status[odi] = fin_status;
+      od.out_steps[odi] = step;
+      if (od.poplog_n) od.poplog_n[odi] = npop;
+      atomicAdd(&counters[CT_EXPANSIONS], step);
+      atomicAdd(&counters[CT_FINISHED], 1);
+    }
+    phase = PH_IDLE;
+  }
+  if (err) {
+    // a workspace cap was hit: report, finish the OD as OVERFLOW so that the batch still terminates
+    atomicExch(&counters[CT_ERROR], 1);
+    if (odi >= 0 && odi < od.n_od) {
+      od.out_len[odi] = 0;
+      od.out_status[odi] = TSG_STATUS_OVERFLOW;
+      od.out_steps[odi] = step;
+      atomicAdd(&counters[CT_FINISHED], 1);
+    }
+    phase = PH_IDLE;
+  }
+  S[SS_PHASE] = phase;
+  S[SS_OD] = odi;
+  S[SS_STEP] = step;
+  S[SS_HEAP_N] = heap_n;
+  S[SS_NODE_N] = node_n;
+  S[SS_EXP_N] = exp_n;
+  S[SS_GEN] = gen;
+  S[SS_WOFF] = woff;
+  S[SS_DES] = des;
+  S[SS_DEFLEN] = deflen;
+  S[SS_MAXSTEP] = max_step;
+  S[SS_ALLOW] = allow;
+  S[SS_WARM_K] = warm_k;
+  S[SS_PLEN] = plen;
+  S[SS_POFF] = poff;
+  S[SS_BEST_LP] = __float_as_int(best_lp);
+  S[SS_BEST_PARENT] = best_parent;
+  S[SS_BEST_RID] = best_rid;
+  S[SS_BEST_TCODE] = best_tcode;
+  S[SS_HAVE_BEST] = have_best;
+  S[SS_NPOP] = npop;
+}
+
+// =====================================================================================
+// host side
+// =====================================================================================
+static int check_engine(const tsg_model* m, const tsg_graph* g, const tsg_od_batch* od, const tsg_engine* e) {
+  if (!g || !e) return TSG_E_INVALID;
+  if (g->n_roads <= 0 || g->max_degree <= 0 || !g->indptr || !g->indices || !g->cost) return TSG_E_INVALID;
+  if (g->max_degree > TSG_MAX_DEGREE) return TSG_E_LIMIT;
+  if (e->slots <= 0 || e->exp_cap <= 0 || e->node_cap <= 0 || e->heap_cap <= 0) return TSG_E_INVALID;
+  if ((unsigned)e->node_cap > TSG_NODE_MASK) return TSG_E_LIMIT;
+  const size_t B = (size_t)e->slots;
+  if (!e->slot_state || e->slot_state_bytes < B * SS_WORDS * 4) return TSG_E_TOO_SMALL;
+  if (!e->heap || e->heap_bytes < B * e->heap_cap * 8) return TSG_E_TOO_SMALL;
+  if (!e->table || e->table_bytes < B * (size_t)g->n_roads * 4) return TSG_E_TOO_SMALL;
+  if (!e->nodes || e->nodes_bytes < B * e->node_cap * ND_WORDS * 4) return TSG_E_TOO_SMALL;
+  if (!e->exp_meta || e->exp_meta_bytes < B * e->exp_cap * EM_WORDS * 4) return TSG_E_TOO_SMALL;
+  if (!e->items || e->items_bytes < B * IT_WORDS * 4) return TSG_E_TOO_SMALL;
+  if (!e->cand_lp || e->cand_lp_bytes < B * (size_t)g->max_degree * 4) return TSG_E_TOO_SMALL;
+  if (!e->counters || e->counters_bytes < 16 * 4) return TSG_E_TOO_SMALL;
+  if (m) {
+    if (m->hp <= 0 || (m->hp % 64) != 0 || m->hp > 512) return TSG_E_INVALID;
+    if (m->n_layers < 1 || m->n_layers > TSG_MAX_LAYERS) return TSG_E_INVALID;
+    if (m->n_roads < g->n_roads) return TSG_E_INVALID;
+    if (!g->lonlat) return TSG_E_INVALID;
+    for (int l = 0; l < m->n_layers; ++l)
+      if (!e->h[l] || !e->c[l] || e->state_bytes < B * e->exp_cap * (size_t)m->hp * 4) return TSG_E_TOO_SMALL;
+  }
+  if (od) {
+    if (od->n_od < 0 || od->lmax <= 0) return TSG_E_INVALID;
+    if (!od->prefix_ptr || !od->prefix_rid || !od->prefix_time || !od->des || !od->default_len || !od->max_step)
+      return TSG_E_INVALID;
+    if (!od->out_rid || !od->out_time || !od->out_len || !od->out_status || !od->out_steps) return TSG_E_INVALID;
+    if (od->poplog_cap > 0 && (!od->poplog_rid || !od->poplog_prio || !od->poplog_n)) return TSG_E_INVALID;
+    if (od->allow_label && !g->label) return TSG_E_INVALID;
+  }
+  return 0;
+}
+
+extern "C" int tsg_engine_reset(const tsg_engine* e, const tsg_graph* g, void* stream) {
+  int rc = check_engine(nullptr, g, nullptr, e);
+  if (rc) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  TSG_HIP_TRY(hipMemsetAsync(e->slot_state, 0, (size_t)e->slots * SS_WORDS * 4, s));  // phase IDLE, gen 0
+  TSG_HIP_TRY(hipMemsetAsync(e->table, 0, (size_t)e->slots * g->n_roads * 4, s));
+  TSG_HIP_TRY(hipMemsetAsync(e->counters, 0, 16 * 4, s));
+  return 0;
+}
+
+extern "C" int tsg_frontier_expand_select(const tsg_graph* g, const tsg_od_batch* od, const tsg_engine* e,
+                                          int32_t superstep, void* stream) {
+  int rc = check_engine(nullptr, g, od, e);
+  if (rc) return rc;
+  EngineDev D;
+  D.e = *e;
+  D.g = *g;
+  D.od = *od;
+  hipLaunchKernelGGL(frontier_kernel, dim3(tsg_cdiv(e->slots, 64)), dim3(64), 0, (hipStream_t)stream, D, superstep);
+  TSG_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int tsg_score_frontier(const tsg_model* m, const tsg_graph* g, const tsg_engine* e, int32_t superstep,
+                                  void* stream) {
+  int rc = check_engine(m, g, nullptr, e);
+  if (rc) return rc;
+  if (!m->out_w || !m->out_b || !m->pfrom || !m->pto || !m->hparams) return TSG_E_INVALID;
+  EngineDev D;
+  D.e = *e;
+  D.g = *g;
+  D.od = tsg_od_batch{};
+  hipLaunchKernelGGL(score_frontier_kernel, dim3(tsg_cdiv(e->slots, 4)), dim3(256), 0, (hipStream_t)stream, *m, D,
+                     superstep);
+  TSG_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int tsg_engine_run(const tsg_model* m, const tsg_graph* g, const tsg_od_batch* od, const tsg_engine* e,
+                              int32_t first_superstep, int32_t n_supersteps, void* stream) {
+  int rc = check_engine(m, g, od, e);
+  if (rc) return rc;
+  if (!m->out_w || !m->out_b || !m->pfrom || !m->pto || !m->hparams) return TSG_E_INVALID;
+  hipStream_t s = (hipStream_t)stream;
+  EngineDev D;
+  D.e = *e;
+  D.g = *g;
+  D.od = *od;
+  const dim3 fgrid(tsg_cdiv(e->slots, 64)), sgrid(tsg_cdiv(e->slots, 4));
+  for (int k = 0; k < n_supersteps; ++k) {
+    const int ss = first_superstep + k;
+    hipLaunchKernelGGL(frontier_kernel, fgrid, dim3(64), 0, s, D, ss);
+    TSG_LAUNCH_CHECK();
+    const int32_t* n_items = e->counters + (ss & 1);
+    for (int l = 0; l < m->n_layers; ++l) {
+      rc = tsg_launch_lstm_layer(m, l, e->slots, n_items, 0, nullptr, nullptr, nullptr, nullptr, e->items, e->exp_cap,
+                                 l > 0 ? e->h[l - 1] : nullptr, e->h[l], e->c[l], s);
+      if (rc) return rc;
+    }
+    hipLaunchKernelGGL(score_frontier_kernel, sgrid, dim3(256), 0, s, *m, D, ss);
+    TSG_LAUNCH_CHECK();
+  }
+  return 0;
+}

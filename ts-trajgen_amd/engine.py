@@ -1,0 +1,376 @@
+"""Host side of the batched A* engine: device tables (model + graph), workspaces, the superstep loop.
+
+Everything numeric happens in libtsg.so; this module only lays tensors out the way include/tsg.h
+documents (gate-interleaved, hidden padded to a multiple of 64), sizes the workspaces and polls the
+completion counter.  PyTorch is used for device memory, streams and one-off layout shuffles.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+
+DEFAULT_SPEED = 8.334           # search.py:11
+
+
+def _ceil(a, b):
+    return (a + b - 1) // b * b
+
+
+def gate_permutation(hidden, hp):
+    """Index tensor `src` of length 4*hp: interleaved column c takes torch gate-major column src[c]
+    (or -1 = zero padding).  Layout: c = (u // 32) * 128 + gate * 32 + u % 32."""
+    c = np.arange(4 * hp)
+    tile, rem = c // 128, c % 128
+    gate, u = rem // 32, tile * 32 + rem % 32
+    return np.where(u < hidden, gate * hidden + u, -1)
+
+
+def _permute_cols(w_t, hidden, hp):
+    """w_t: [K, 4*hidden] (torch gate-major columns) -> [K, 4*hp] interleaved, zero padded."""
+    src = gate_permutation(hidden, hp)
+    out = torch.zeros((w_t.shape[0], 4 * hp), dtype=torch.float32, device=w_t.device)
+    valid = torch.from_numpy(np.flatnonzero(src >= 0)).to(w_t.device)
+    out[:, valid] = w_t[:, torch.from_numpy(src[src >= 0]).to(w_t.device)]
+    return out
+
+
+def _pad_rows(w, rows):
+    if w.shape[0] == rows:
+        return w.contiguous()
+    out = torch.zeros((rows,) + tuple(w.shape[1:]), dtype=w.dtype, device=w.device)
+    out[:w.shape[0]] = w
+    return out
+
+
+def gemm(a, bt, bias=None):
+    """C = A . Bt (+ bias) through tsg_gemm_f32 (fp32 MFMA)."""
+    L = _lib.lib()
+    a = a.contiguous().float()
+    bt = bt.contiguous().float()
+    m, k = a.shape
+    n = bt.shape[1]
+    out = torch.empty((m, n), dtype=torch.float32, device=a.device)
+    if bias is not None:
+        bias = bias.contiguous().float()
+    with torch.cuda.device(a.device):
+        _lib.check(L.tsg_gemm_f32(_lib.ptr(a), k, _lib.ptr(bt), n, _lib.ptr(bias), _lib.ptr(out), n, m, n, k,
+                                  _lib.current_stream()), 'tsg_gemm_f32')
+    return out
+
+
+class ModelTables(object):
+    """Device tables of one GeneratorV4 (generator_v4.py:16-29) in the layout of `tsg_model`."""
+
+    def __init__(self, generator):
+        g, h = generator.function_g, generator.function_h
+        dev = generator.w1.device
+        if dev.type != 'cuda':
+            raise RuntimeError('ModelTables needs the generator on a HIP device (no CPU fallback)')
+        self.device = dev
+        with torch.no_grad():
+            H = g.hidden_size
+            hp = _ceil(H, 64)
+            er = g.road_emb_size
+            nl = g.lstm_layer_num
+            if nl > _lib.TSG_MAX_LAYERS:
+                raise ValueError('at most %d LSTM layers' % _lib.TSG_MAX_LAYERS)
+            sd = {k: v.detach().float() for k, v in g.state_dict().items()}
+            w_ih0 = sd['lstm.weight_ih_l0']                                  # (4H, Er+Et)
+            self.xproj = gemm(sd['road_emb.weight'], _permute_cols(w_ih0[:, :er].t().contiguous(), H, hp))
+            b0 = _permute_cols((sd['lstm.bias_ih_l0'] + sd['lstm.bias_hh_l0']).unsqueeze(0), H, hp).squeeze(0)
+            self.tproj = gemm(sd['time_emb.weight'], _permute_cols(w_ih0[:, er:].t().contiguous(), H, hp), b0)
+            self.whh0_t = _pad_rows(_permute_cols(sd['lstm.weight_hh_l0'].t().contiguous(), H, hp), hp)
+            self.wl_t = [None] * _lib.TSG_MAX_LAYERS
+            self.bl = [None] * _lib.TSG_MAX_LAYERS
+            for l in range(1, nl):
+                top = _pad_rows(_permute_cols(sd['lstm.weight_ih_l%d' % l].t().contiguous(), H, hp), hp)
+                bot = _pad_rows(_permute_cols(sd['lstm.weight_hh_l%d' % l].t().contiguous(), H, hp), hp)
+                self.wl_t[l] = torch.cat([top, bot], dim=0).contiguous()
+                self.bl[l] = _permute_cols((sd['lstm.bias_ih_l%d' % l] + sd['lstm.bias_hh_l%d' % l]).unsqueeze(0),
+                                           H, hp).squeeze(0).contiguous()
+            ow = sd['out_fc.weight']                                        # (road_num, H)
+            self.out_w = torch.zeros((ow.shape[0], hp), dtype=torch.float32, device=dev)
+            self.out_w[:, :H] = ow
+            self.out_b = sd['out_fc.bias'].contiguous()
+            # function H: cached GAT node embedding, then the factored emb_fc (distance_gat_fc.py:129-131)
+            h._setup_node_emb()
+            emb = h.node_emb_feature
+            F = emb.shape[1]
+            we = h.emb_fc.weight.detach().float()                           # (10, 2F)
+            self.pfrom = gemm(emb, we[:, :F].t().contiguous())
+            self.pto = gemm(emb, we[:, F:].t().contiguous(), h.emb_fc.bias.detach().float())
+            self.hparams = torch.cat([h.dis_fc.weight.detach().float().reshape(-1),
+                                      h.dis_fc.bias.detach().float().reshape(-1),
+                                      h.out_fc.weight.detach().float().reshape(-1),
+                                      h.out_fc.bias.detach().float().reshape(-1),
+                                      generator.w1.detach().float().reshape(-1)]).contiguous()
+            self.hidden, self.hp, self.n_layers = H, hp, nl
+            self.n_roads_g = ow.shape[0]
+            self.n_nodes_h = emb.shape[0]
+            self.n_time = sd['time_emb.weight'].shape[0]
+        m = _lib.Model()
+        m.n_roads = min(self.n_roads_g, self.n_nodes_h)
+        m.n_time, m.hp, m.n_layers = self.n_time, hp, nl
+        m.xproj, m.tproj, m.whh0_t = _lib.ptr(self.xproj), _lib.ptr(self.tproj), _lib.ptr(self.whh0_t)
+        for l in range(1, nl):
+            m.wl_t[l] = self.wl_t[l].data_ptr()
+            m.bl[l] = self.bl[l].data_ptr()
+        m.out_w, m.out_b = _lib.ptr(self.out_w), _lib.ptr(self.out_b)
+        m.pfrom, m.pto, m.hparams = _lib.ptr(self.pfrom), _lib.ptr(self.pto), _lib.ptr(self.hparams)
+        self.c_model = m
+
+    @torch.no_grad()
+    def predict(self, trace_loc, trace_time, des, candidate_set, candidate_dis, trace_mask=None):
+        """GeneratorV4.predict for (B, L) prefixes and (B, C) candidates; returns (p, g, h), each (B, C)."""
+        L = _lib.lib()
+        dev = self.device
+        B, T = trace_loc.shape
+        Cn = candidate_set.shape[1]
+        if Cn > _lib.TSG_MAX_DEGREE:
+            raise ValueError('at most %d candidates per row' % _lib.TSG_MAX_DEGREE)
+        loc = trace_loc.to(dev).to(torch.int32).contiguous()
+        tim = trace_time.to(dev).to(torch.int32).contiguous()
+        if int(loc.min()) < 0 or int(loc.max()) >= self.xproj.shape[0]:
+            raise IndexError('road id outside the road embedding table')
+        if int(tim.min()) < 0 or int(tim.max()) >= self.n_time:
+            raise IndexError('time code outside the time embedding table')
+        cand = candidate_set.to(dev).to(torch.int32).contiguous()
+        if int(cand.min()) < 0 or int(cand.max()) >= self.c_model.n_roads:
+            raise IndexError('candidate id outside the model tables')
+        d32 = des.to(dev).to(torch.int32).reshape(B).contiguous()
+        if int(d32.min()) < 0 or int(d32.max()) >= self.n_nodes_h:
+            raise IndexError('destination id outside the node embedding table')
+        dis = candidate_dis.to(dev).float().contiguous()
+        if trace_mask is not None:
+            lens = trace_mask.to(dev).sum(dim=1).to(torch.int64)
+        else:
+            lens = torch.full((B,), T, dtype=torch.int64, device=dev)
+        hp, nl = self.hp, self.n_layers
+        hs = [torch.empty((B * T, hp), dtype=torch.float32, device=dev) for _ in range(nl)]
+        cs = [torch.empty((B * T, hp), dtype=torch.float32, device=dev) for _ in range(nl)]
+        base = torch.arange(B, dtype=torch.int64, device=dev) * T
+        stream = _lib.current_stream()
+        with torch.cuda.device(dev):
+            for t in range(T):
+                out_idx = (base + t).contiguous()
+                prev_idx = (base + t - 1).contiguous() if t > 0 else torch.full_like(base, -1)
+                rid_t = loc[:, t].contiguous()
+                tc_t = tim[:, t].contiguous()
+                for l in range(nl):
+                    s = _lib.LstmStep()
+                    s.layer, s.n_rows_host, s.n_rows_dev = l, B, None
+                    s.prev_idx, s.out_idx = _lib.ptr(prev_idx), _lib.ptr(out_idx)
+                    s.rid, s.tcode = _lib.ptr(rid_t), _lib.ptr(tc_t)
+                    s.h_below = _lib.ptr(hs[l - 1]) if l > 0 else None
+                    s.h, s.c = _lib.ptr(hs[l]), _lib.ptr(cs[l])
+                    s.state_rows = B * T
+                    _lib.check(L.tsg_lstm_step_batched(C.byref(self.c_model), C.byref(s), stream),
+                               'tsg_lstm_step_batched')
+            chain_ptr = torch.zeros(B + 1, dtype=torch.int32, device=dev)
+            chain_ptr[1:] = torch.cumsum(lens, 0).to(torch.int32)
+            pos = torch.arange(T, dtype=torch.int64, device=dev).unsqueeze(0).expand(B, T)
+            keep = pos < lens.unsqueeze(1)
+            chain = (base.unsqueeze(1) + pos)[keep].contiguous()
+            cand_ptr = (torch.arange(B + 1, dtype=torch.int32, device=dev) * Cn).contiguous()
+            prob = torch.empty((B, Cn), dtype=torch.float32, device=dev)
+            pg = torch.empty_like(prob)
+            ph = torch.empty_like(prob)
+            sb = _lib.ScoreBatch()
+            sb.n_rows = B
+            sb.chain_ptr, sb.chain, sb.h_top = _lib.ptr(chain_ptr), _lib.ptr(chain), _lib.ptr(hs[nl - 1])
+            sb.cand_ptr, sb.cand, sb.dis, sb.des = _lib.ptr(cand_ptr), _lib.ptr(cand), _lib.ptr(dis), _lib.ptr(d32)
+            sb.prob, sb.prob_g, sb.prob_h = _lib.ptr(prob), _lib.ptr(pg), _lib.ptr(ph)
+            _lib.check(L.tsg_score_candidates(C.byref(self.c_model), C.byref(sb), stream), 'tsg_score_candidates')
+        return prob, pg, ph
+
+
+class GraphTables(object):
+    """Device substrate of a road network in the layout of `tsg_graph`."""
+
+    def __init__(self, device, adjacent_list, road_center_gps, road_length, road_time_distribution,
+                 num_roads=None, rid_label=None):
+        from .synth import csr_from_adjacent_list
+        self.device = torch.device(device)
+        if num_roads is None:
+            num_roads = int(road_time_distribution.shape[1])
+        n = self.num_roads = int(num_roads)
+        indptr, indices = csr_from_adjacent_list(adjacent_list, n)
+        if len(indices) and (indices.min() < 0 or indices.max() >= n):
+            raise ValueError('adjacent_list refers to a road id outside [0, %d)' % n)
+        deg = np.diff(indptr)
+        self.max_degree = int(max(1, deg.max() if len(deg) else 1))
+        if self.max_degree > _lib.TSG_MAX_DEGREE:
+            raise ValueError('out-degree %d exceeds the kernel limit %d' % (self.max_degree, _lib.TSG_MAX_DEGREE))
+        lonlat = np.zeros((n, 2), dtype=np.float64)
+        for r in range(n):
+            gps = road_center_gps.get(str(r)) if road_center_gps is not None else None
+            if gps is not None:
+                lonlat[r, 0], lonlat[r, 1] = gps[0], gps[1]
+        # search.py:75 (astype(int)) and :376-381: cost = rtd if rtd != 1 else int(round(length / 8.334))
+        rtd = np.asarray(road_time_distribution).astype(int)[:, :n]
+        default = np.zeros(n, dtype=np.int64)
+        for r in range(n):
+            ln = road_length.get(str(r)) if road_length is not None else None
+            default[r] = int(round(ln / DEFAULT_SPEED)) if ln is not None else 1
+        cost = np.where(rtd != 1, rtd, default[None, :]).astype(np.int32)
+        self.indptr_np, self.indices_np = indptr, indices
+        dev = self.device
+        self.indptr = torch.from_numpy(indptr).to(dev)
+        self.indices = torch.from_numpy(indices if len(indices) else np.zeros(1, np.int32)).to(dev)
+        self.lonlat = torch.from_numpy(lonlat).to(dev)
+        self.cost = torch.from_numpy(np.ascontiguousarray(cost)).to(dev)
+        self.label = None
+        if rid_label is not None:
+            self.set_labels(rid_label)
+        self._build()
+
+    def set_labels(self, rid_label):
+        lab = np.asarray(rid_label, dtype=np.int32)
+        if lab.shape != (self.num_roads,):
+            raise ValueError('rid_label must have one entry per road')
+        self.label = torch.from_numpy(lab).to(self.device)
+        self._build()
+
+    def _build(self):
+        g = _lib.Graph()
+        g.n_roads, g.max_degree = self.num_roads, self.max_degree
+        g.indptr, g.indices, g.lonlat = _lib.ptr(self.indptr), _lib.ptr(self.indices), _lib.ptr(self.lonlat)
+        g.cost, g.label = _lib.ptr(self.cost), _lib.ptr(self.label)
+        self.c_graph = g
+
+
+class AStarEngine(object):
+    """Workspaces + superstep loop of the batched A* (tsg_engine_run)."""
+
+    def __init__(self, tables, graph, slots, max_step, max_prefix=1, lmax=256):
+        self.tables, self.graph = tables, graph
+        dev = self.device = tables.device
+        n = graph.num_roads
+        self.slots = B = int(slots)
+        self.max_step, self.max_prefix, self.lmax = int(max_step), int(max_prefix), int(lmax)
+        self.exp_cap = self.max_prefix + self.max_step
+        self.node_cap = int(min(n, 1 + self.max_step * graph.max_degree)) + 1
+        self.heap_cap = 1 + self.max_step * graph.max_degree
+        if self.node_cap >= (1 << 20):
+            raise ValueError('node_cap %d exceeds 2^20-1' % self.node_cap)
+        hp, nl = tables.hp, tables.n_layers
+        i32, f32 = torch.int32, torch.float32
+        self.slot_state = torch.zeros((B, 32), dtype=i32, device=dev)
+        self.heap = torch.empty((B, self.heap_cap), dtype=torch.int64, device=dev)
+        self.table = torch.zeros((B, n), dtype=i32, device=dev)
+        self.nodes = torch.empty((B, self.node_cap, 8), dtype=i32, device=dev)
+        self.exp_meta = torch.empty((B, self.exp_cap, 4), dtype=i32, device=dev)
+        self.h = [torch.empty((B * self.exp_cap, hp), dtype=f32, device=dev) for _ in range(nl)]
+        self.c = [torch.empty((B * self.exp_cap, hp), dtype=f32, device=dev) for _ in range(nl)]
+        self.items = torch.empty((B, 8), dtype=i32, device=dev)
+        self.cand_lp = torch.empty((B, graph.max_degree), dtype=f32, device=dev)
+        self.counters = torch.zeros(16, dtype=i32, device=dev)
+        e = _lib.Engine()
+        e.slots, e.exp_cap, e.node_cap, e.heap_cap = B, self.exp_cap, self.node_cap, self.heap_cap
+        for name in ('slot_state', 'heap', 'table', 'nodes', 'exp_meta', 'items', 'cand_lp', 'counters'):
+            t = getattr(self, name)
+            setattr(e, name, t.data_ptr())
+            setattr(e, name + '_bytes', t.numel() * t.element_size())
+        for l in range(nl):
+            e.h[l] = self.h[l].data_ptr()
+            e.c[l] = self.c[l].data_ptr()
+        e.state_bytes = self.h[0].numel() * 4
+        self.c_engine = e
+        self.last_stats = {}
+
+    @staticmethod
+    def bytes_per_slot(tables, graph, max_step, max_prefix=1):
+        exp_cap = max_prefix + max_step
+        node_cap = min(graph.num_roads, 1 + max_step * graph.max_degree) + 1
+        heap_cap = 1 + max_step * graph.max_degree
+        return (2 * tables.n_layers * exp_cap * tables.hp * 4 + heap_cap * 8 + graph.num_roads * 4
+                + node_cap * 32 + exp_cap * 16 + 32 * 4 + 32 + graph.max_degree * 4)
+
+    @torch.no_grad()
+    def run(self, prefix_ptr, prefix_rid, prefix_time, des, default_len, max_step, allow_label=None,
+            poplog_cap=0, chunk=32, return_device=False):
+        """Run all OD pairs; returns dict(rid [n, lmax], time, len, status, steps[, poplog_*])."""
+        L = _lib.lib()
+        dev = self.device
+        i32 = torch.int32
+
+        def dv(a):
+            if torch.is_tensor(a):
+                return a.to(dev).to(i32).contiguous()
+            return torch.from_numpy(np.ascontiguousarray(np.asarray(a, dtype=np.int32))).to(dev)
+        prefix_ptr, prefix_rid, prefix_time = dv(prefix_ptr), dv(prefix_rid), dv(prefix_time)
+        des, default_len, max_step_t = dv(des), dv(default_len), dv(max_step)
+        n_od = int(des.numel())
+        if n_od == 0:
+            z = torch.zeros((0,), dtype=i32)
+            return {'rid': torch.zeros((0, self.lmax), dtype=i32), 'time': torch.zeros((0, self.lmax), dtype=i32),
+                    'len': z, 'status': z, 'steps': z}
+        # host-side validation of everything the kernels index with
+        n = self.graph.num_roads
+        plen = (prefix_ptr[1:] - prefix_ptr[:-1])
+        if int(prefix_ptr.numel()) != n_od + 1 or int(plen.min()) < 1 or int(plen.max()) > self.max_prefix:
+            raise ValueError('every OD needs a prefix of 1..%d elements' % self.max_prefix)
+        if int(prefix_ptr[-1]) != int(prefix_rid.numel()) or prefix_rid.numel() != prefix_time.numel():
+            raise ValueError('prefix_ptr does not match prefix arrays')
+        if int(prefix_rid.min()) < 0 or int(prefix_rid.max()) >= n or int(des.min()) < 0 or int(des.max()) >= n:
+            raise IndexError('road id outside [0, %d)' % n)
+        if int(des.max()) >= self.tables.n_nodes_h or n > self.tables.c_model.n_roads:
+            raise IndexError('road id outside the model tables')
+        if int(prefix_time.min()) < 0 or int(prefix_time.max()) >= min(2880, self.tables.n_time):
+            raise IndexError('time code outside [0, 2880)')
+        if int(max_step_t.max()) > self.max_step or int(max_step_t.min()) < 0:
+            raise ValueError('max_step exceeds the engine capacity %d' % self.max_step)
+        od = _lib.OdBatch()
+        od.n_od, od.lmax = n_od, self.lmax
+        od.prefix_ptr, od.prefix_rid, od.prefix_time = _lib.ptr(prefix_ptr), _lib.ptr(prefix_rid), _lib.ptr(prefix_time)
+        od.des, od.default_len, od.max_step = _lib.ptr(des), _lib.ptr(default_len), _lib.ptr(max_step_t)
+        allow_t = None
+        if allow_label is not None:
+            if self.graph.label is None:
+                raise ValueError('allow_label needs GraphTables.set_labels()')
+            allow_t = dv(allow_label)
+            od.allow_label = _lib.ptr(allow_t)
+        out_rid = torch.zeros((n_od, self.lmax), dtype=i32, device=dev)
+        out_time = torch.zeros((n_od, self.lmax), dtype=i32, device=dev)
+        out_len = torch.zeros(n_od, dtype=i32, device=dev)
+        out_status = torch.zeros(n_od, dtype=i32, device=dev)
+        out_steps = torch.zeros(n_od, dtype=i32, device=dev)
+        od.out_rid, od.out_time, od.out_len = _lib.ptr(out_rid), _lib.ptr(out_time), _lib.ptr(out_len)
+        od.out_status, od.out_steps = _lib.ptr(out_status), _lib.ptr(out_steps)
+        pl_rid = pl_prio = pl_n = None
+        od.poplog_cap = int(poplog_cap)
+        if poplog_cap > 0:
+            pl_rid = torch.zeros((n_od, poplog_cap), dtype=i32, device=dev)
+            pl_prio = torch.zeros((n_od, poplog_cap), dtype=torch.float32, device=dev)
+            pl_n = torch.zeros(n_od, dtype=i32, device=dev)
+            od.poplog_rid, od.poplog_prio, od.poplog_n = _lib.ptr(pl_rid), _lib.ptr(pl_prio), _lib.ptr(pl_n)
+        stream = _lib.current_stream()
+        m, g, e = self.tables.c_model, self.graph.c_graph, self.c_engine
+        supersteps = 0
+        with torch.cuda.device(dev):
+            _lib.check(L.tsg_engine_reset(C.byref(e), C.byref(g), stream), 'tsg_engine_reset')
+            # every superstep each unfinished slot advances by >= 1 expansion / prefix element / finished OD
+            bound = (math.ceil(n_od / self.slots) + 1) * (self.max_step + self.max_prefix + 2) + 8
+            while True:
+                _lib.check(L.tsg_engine_run(C.byref(m), C.byref(g), C.byref(od), C.byref(e), supersteps, chunk,
+                                            stream), 'tsg_engine_run')
+                supersteps += chunk
+                cnt = self.counters.cpu()
+                if int(cnt[3]) >= n_od:
+                    break
+                if supersteps > bound:
+                    raise RuntimeError('A* engine did not finish within %d supersteps (finished %d of %d)'
+                                       % (bound, int(cnt[3]), n_od))
+        if int(cnt[6]) != 0:
+            raise RuntimeError('A* engine hit a workspace cap (node/heap/exp capacity)')
+        self.last_stats = {'supersteps': supersteps, 'expansions': int(cnt[4]), 'model_evals': int(cnt[5]),
+                           'n_od': n_od}
+        res = {'rid': out_rid, 'time': out_time, 'len': out_len, 'status': out_status, 'steps': out_steps}
+        if poplog_cap > 0:
+            res.update({'poplog_rid': pl_rid, 'poplog_prio': pl_prio, 'poplog_n': pl_n})
+        if not return_device:
+            res = {k: v.cpu() for k, v in res.items()}
+        return res

@@ -1,0 +1,75 @@
+"""DistanceGatFC drop-in (function H; reference: generator/distance_gat_fc.py:9-42 constructor,
+:118-157 predict_cache/predict_next, :189-223 node-embedding cache).  Inference-only."""
+import ctypes as C
+
+import torch
+import torch.nn as nn
+
+from .. import _lib
+from .gat import GATLayerImp3
+
+
+class DistanceGatFC(nn.Module):
+    def __init__(self, config, data_feature):
+        super().__init__()
+        self.embed_dim = config['embed_dim']
+        self.num_of_heads = config['num_of_heads']
+        self.concat = config['concat']
+        self.device = config['device']
+        self.gps_emb_dim = config['gps_emb_dim']
+        self.distance_mode = config['distance_mode']
+        self.no_gps_emb = config.get('no_gps_emb', False)
+        self.adj_mx = data_feature.get('adj_mx')
+        self.Apt = torch.LongTensor([self.adj_mx.row.tolist(), self.adj_mx.col.tolist()]).to(self.device)
+        self.node_features = data_feature['node_features']
+        if not self.no_gps_emb:
+            self.feature_dim = self.node_features.shape[1] - 2 + self.gps_emb_dim * 2
+        else:
+            self.feature_dim = self.node_features.shape[1]
+        self.gat_encoder = GATLayerImp3(num_in_features=self.feature_dim, num_out_features=self.embed_dim,
+                                        num_of_heads=self.num_of_heads, concat=self.concat, device=self.device)
+        if not self.no_gps_emb:
+            self.lat_embed = nn.Embedding(num_embeddings=data_feature['img_height'], embedding_dim=self.gps_emb_dim)
+            self.lon_embed = nn.Embedding(num_embeddings=data_feature['img_width'], embedding_dim=self.gps_emb_dim)
+        self.emb_fc = nn.Linear(in_features=self.embed_dim * 2, out_features=10)
+        self.dis_fc = nn.Linear(in_features=1, out_features=10)
+        self.out_fc = nn.Linear(in_features=20, out_features=1)
+        self.node_emb_feature = None
+
+    def _dev(self):
+        return self.emb_fc.weight.device
+
+    @torch.no_grad()
+    def input_features(self):
+        """[lon_embed | lat_embed | raw[:, :-2]] per node (distance_gat_fc.py:191-199), built on the device."""
+        dev = self._dev()
+        nf = self.node_features.to(dev).contiguous().float()
+        if self.no_gps_emb:
+            return nf
+        L = _lib.lib()
+        n, fraw = nf.shape
+        x = torch.empty((n, self.feature_dim), dtype=torch.float32, device=dev)
+        flag = torch.zeros(1, dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(L.tsg_gat_build_input(_lib.ptr(nf), n, fraw, _lib.ptr(self.lon_embed.weight.detach()),
+                                             self.lon_embed.num_embeddings,
+                                             _lib.ptr(self.lat_embed.weight.detach()),
+                                             self.lat_embed.num_embeddings, self.gps_emb_dim, _lib.ptr(x),
+                                             _lib.ptr(flag), _lib.current_stream()), 'tsg_gat_build_input')
+        if int(flag.item()) != 0:
+            raise IndexError('lon/lat grid cell outside the lon_embed / lat_embed tables')
+        return x
+
+    def update_node_emb(self):
+        dev = self._dev()
+        if dev.type != 'cuda':
+            raise RuntimeError('DistanceGatFC needs its parameters on a HIP device (no CPU fallback)')
+        x = self.input_features()
+        self.node_emb_feature = self.gat_encoder((x, self.Apt.to(dev)))[0]
+
+    def _setup_node_emb(self):
+        if self.node_emb_feature is None:
+            self.update_node_emb()
+
+    def forward(self, *args, **kwargs):
+        raise NotImplementedError('training forward of function H is outside the generation path')
