@@ -221,7 +221,9 @@ typedef struct tsg_engine {
   int32_t* items;       size_t items_bytes;       /* [B][8] work items of the current superstep */
   float* cand_lp;       size_t cand_lp_bytes;     /* [B][max_degree] */
   int32_t* counters;    size_t counters_bytes;    /* [16]: 0,1 item counters (ping-pong), 2 next OD, 3 finished ODs,
-                                                     4 total expansions, 5 total model evaluations, 6 error flag */
+                                                     4 total expansions, 5 total model evaluations, 6 error flag,
+                                                     7 total work items (LSTM rows), 8-9 (u64) sum of attention chain
+                                                     lengths, 10-11 (u64) sum of scored candidates */
 } tsg_engine;
 
 /* Reset slot states and counters for a new OD batch (enqueues memsets + an init kernel). */
@@ -231,6 +233,14 @@ int tsg_engine_reset(const tsg_engine* e, const tsg_graph* g, void* stream);
  * selects the ping-pong item counter).  Poll counters[3] == n_od for completion. */
 int tsg_engine_run(const tsg_model* m, const tsg_graph* g, const tsg_od_batch* od, const tsg_engine* e,
                    int32_t first_superstep, int32_t n_supersteps, void* stream);
+
+/* Measurement variant of tsg_engine_run: identical launches, each bracketed by HIP events on `stream`.
+ * SYNCHRONISES the stream before returning.  Adds per-kernel elapsed ms and launch counts to
+ * ms_sum_host / launches_host, both HOST arrays of 2 + TSG_MAX_LAYERS entries:
+ * [0] frontier kernel, [1] scoring kernel, [2 + l] LSTM layer l.  (No counterpart in the reference.) */
+int tsg_engine_run_profiled(const tsg_model* m, const tsg_graph* g, const tsg_od_batch* od, const tsg_engine* e,
+                            int32_t first_superstep, int32_t n_supersteps, void* stream, float* ms_sum_host,
+                            int32_t* launches_host);
 
 /* The two kernels of one superstep, individually launchable (tests, profiling). */
 int tsg_frontier_expand_select(const tsg_graph* g, const tsg_od_batch* od, const tsg_engine* e, int32_t superstep,

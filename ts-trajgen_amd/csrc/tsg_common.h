@@ -46,7 +46,8 @@ enum {
 };
 enum { PH_IDLE = 0, PH_WARMUP = 1, PH_SEARCH = 2, PH_EXPANDED = 3, PH_DONE = 4 };
 // counters
-enum { CT_ITEMS0 = 0, CT_ITEMS1 = 1, CT_NEXT_OD = 2, CT_FINISHED = 3, CT_EXPANSIONS = 4, CT_MODEL_EVALS = 5, CT_ERROR = 6 };
+enum { CT_ITEMS0 = 0, CT_ITEMS1 = 1, CT_NEXT_OD = 2, CT_FINISHED = 3, CT_EXPANSIONS = 4, CT_MODEL_EVALS = 5, CT_ERROR = 6, CT_ITEMS_TOTAL = 7,
+       CT_CHAIN_SUM = 8 /* u64: words 8,9 */, CT_CAND_SUM = 10 /* u64: words 10,11 */ };
 // work item words ([B][8] int32)
 enum { IT_SLOT = 0, IT_EXP, IT_PARENT, IT_RID, IT_TCODE, IT_NCAND, IT_DES, IT_LP, IT_WORDS = 8 };
 // node record words ([B][node_cap][8] int32)

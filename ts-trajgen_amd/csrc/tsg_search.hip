@@ -1,5 +1,7 @@
 // Batched A* engine kernels: candidate scoring (one wave64 per expanded node) and the per-OD
 // frontier kernel (heapq-exact priority queue, closed set, relax rules of search.py:385-419).
+#include <new>
+
 #include "tsg_device.h"
 
 int tsg_launch_lstm_layer(const tsg_model* m, int layer, int max_rows, const int32_t* n_rows_dev, int n_rows_host,
@@ -71,8 +73,11 @@ __global__ __launch_bounds__(256) void score_frontier_kernel(tsg_model m, Engine
   const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   int32_t* counters = D.e.counters;
-  if (blockIdx.x == 0 && threadIdx.x == 0) counters[(superstep + 1) & 1] = 0;  // next superstep's item counter
   const int n_items = counters[superstep & 1];
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    counters[(superstep + 1) & 1] = 0;  // next superstep's item counter
+    atomicAdd(&counters[CT_ITEMS_TOTAL], n_items);
+  }
   if (idx >= n_items) return;
   const int32_t* it = D.e.items + (size_t)idx * IT_WORDS;
   const int ncand = it[IT_NCAND];
@@ -88,7 +93,9 @@ __global__ __launch_bounds__(256) void score_frontier_kernel(tsg_model m, Engine
   AttnAcc acc;
   attn_init(acc);
   int cur = e;
+  int chain_len = 0;
   while (cur >= 0) {  // ancestor chain: parent pointers of closed (immutable) nodes
+    ++chain_len;
     const int nxt = em[(size_t)cur * EM_WORDS + EM_PARENT];
     const float* kr = htop + (size_t)cur * hp;
 #pragma unroll
@@ -110,7 +117,11 @@ __global__ __launch_bounds__(256) void score_frontier_kernel(tsg_model m, Engine
   }
   const float f = score_row(m, pooled, J, lane, ncand, my_cand, my_dis, des, nullptr, nullptr);
   if (lane < ncand) D.e.cand_lp[(size_t)b * D.g.max_degree + lane] = logf(f) + lp_parent;  // search.py:370-373
-  if (lane == 0) atomicAdd(&counters[CT_MODEL_EVALS], 1);
+  if (lane == 0) {
+    atomicAdd(&counters[CT_MODEL_EVALS], 1);
+    atomicAdd(reinterpret_cast<unsigned long long*>(&counters[CT_CHAIN_SUM]), (unsigned long long)chain_len);
+    atomicAdd(reinterpret_cast<unsigned long long*>(&counters[CT_CAND_SUM]), (unsigned long long)ncand);
+  }
 }
 
 // =====================================================================================
@@ -579,5 +590,76 @@ extern "C" int tsg_engine_run(const tsg_model* m, const tsg_graph* g, const tsg_
     hipLaunchKernelGGL(score_frontier_kernel, sgrid, dim3(256), 0, s, *m, D, ss);
     TSG_LAUNCH_CHECK();
   }
+  return 0;
+}
+
+// Profiling variant: same launches, each bracketed by HIP events on `stream`; synchronises the stream
+// before returning (the caller polls the completion counter after every chunk anyway).
+extern "C" int tsg_engine_run_profiled(const tsg_model* m, const tsg_graph* g, const tsg_od_batch* od,
+                                       const tsg_engine* e, int32_t first_superstep, int32_t n_supersteps,
+                                       void* stream, float* ms_sum_host, int32_t* launches_host) {
+  int rc = check_engine(m, g, od, e);
+  if (rc) return rc;
+  if (!ms_sum_host || !launches_host || n_supersteps <= 0 || n_supersteps > 4096) return TSG_E_INVALID;
+  if (!m->out_w || !m->out_b || !m->pfrom || !m->pto || !m->hparams) return TSG_E_INVALID;
+  hipStream_t s = (hipStream_t)stream;
+  EngineDev D;
+  D.e = *e;
+  D.g = *g;
+  D.od = *od;
+  const int nk = 2 + m->n_layers;  // frontier, score, lstm layers
+  const int nev = n_supersteps * nk * 2;
+  hipEvent_t* ev = new (std::nothrow) hipEvent_t[nev];
+  if (!ev) return TSG_E_INVALID;
+  for (int i = 0; i < nev; ++i)
+    if (hipEventCreate(&ev[i]) != hipSuccess) {
+      for (int j = 0; j < i; ++j) (void)hipEventDestroy(ev[j]);
+      delete[] ev;
+      return TSG_E_INVALID;
+    }
+  const dim3 fgrid(tsg_cdiv(e->slots, 64)), sgrid(tsg_cdiv(e->slots, 4));
+  int q = 0;
+  rc = 0;
+  for (int k = 0; k < n_supersteps && rc == 0; ++k) {
+    const int ss = first_superstep + k;
+    (void)hipEventRecord(ev[q++], s);
+    hipLaunchKernelGGL(frontier_kernel, fgrid, dim3(64), 0, s, D, ss);
+    (void)hipEventRecord(ev[q++], s);
+    const int32_t* n_items = e->counters + (ss & 1);
+    for (int l = 0; l < m->n_layers && rc == 0; ++l) {
+      (void)hipEventRecord(ev[q++], s);
+      rc = tsg_launch_lstm_layer(m, l, e->slots, n_items, 0, nullptr, nullptr, nullptr, nullptr, e->items, e->exp_cap,
+                                 l > 0 ? e->h[l - 1] : nullptr, e->h[l], e->c[l], s);
+      (void)hipEventRecord(ev[q++], s);
+    }
+    (void)hipEventRecord(ev[q++], s);
+    hipLaunchKernelGGL(score_frontier_kernel, sgrid, dim3(256), 0, s, *m, D, ss);
+    (void)hipEventRecord(ev[q++], s);
+  }
+  hipError_t he = hipStreamSynchronize(s);
+  if (rc == 0 && he == hipSuccess) {
+    q = 0;
+    for (int k = 0; k < n_supersteps; ++k) {
+      float ms = 0.f;
+      (void)hipEventElapsedTime(&ms, ev[q], ev[q + 1]);
+      q += 2;
+      ms_sum_host[0] += ms;
+      launches_host[0] += 1;
+      for (int l = 0; l < m->n_layers; ++l) {
+        (void)hipEventElapsedTime(&ms, ev[q], ev[q + 1]);
+        q += 2;
+        ms_sum_host[2 + l] += ms;
+        launches_host[2 + l] += 1;
+      }
+      (void)hipEventElapsedTime(&ms, ev[q], ev[q + 1]);
+      q += 2;
+      ms_sum_host[1] += ms;
+      launches_host[1] += 1;
+    }
+  }
+  for (int i = 0; i < nev; ++i) (void)hipEventDestroy(ev[i]);
+  delete[] ev;
+  if (rc) return rc;
+  if (he != hipSuccess) return -(int)he - 1000;
   return 0;
 }

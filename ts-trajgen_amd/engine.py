@@ -291,7 +291,7 @@ class AStarEngine(object):
 
     @torch.no_grad()
     def run(self, prefix_ptr, prefix_rid, prefix_time, des, default_len, max_step, allow_label=None,
-            poplog_cap=0, chunk=32, return_device=False):
+            poplog_cap=0, chunk=32, return_device=False, profile_every=0):
         """Run all OD pairs; returns dict(rid [n, lmax], time, len, status, steps[, poplog_*])."""
         L = _lib.lib()
         dev = self.device
@@ -350,15 +350,28 @@ class AStarEngine(object):
         stream = _lib.current_stream()
         m, g, e = self.tables.c_model, self.graph.c_graph, self.c_engine
         supersteps = 0
+        nk = 2 + _lib.TSG_MAX_LAYERS
+        prof_ms = (C.c_float * nk)()
+        prof_n = (C.c_int32 * nk)()
+        prof_items = 0
+        chunk_i = 0
         with torch.cuda.device(dev):
             _lib.check(L.tsg_engine_reset(C.byref(e), C.byref(g), stream), 'tsg_engine_reset')
             # every superstep each unfinished slot advances by >= 1 expansion / prefix element / finished OD
             bound = (math.ceil(n_od / self.slots) + 1) * (self.max_step + self.max_prefix + 2) + 8
             while True:
-                _lib.check(L.tsg_engine_run(C.byref(m), C.byref(g), C.byref(od), C.byref(e), supersteps, chunk,
-                                            stream), 'tsg_engine_run')
+                if profile_every and chunk_i % profile_every == 0:
+                    items0 = int(self.counters[7])
+                    _lib.check(L.tsg_engine_run_profiled(C.byref(m), C.byref(g), C.byref(od), C.byref(e), supersteps,
+                                                         chunk, stream, prof_ms, prof_n), 'tsg_engine_run_profiled')
+                    cnt = self.counters.cpu()
+                    prof_items += int(cnt[7]) - items0
+                else:
+                    _lib.check(L.tsg_engine_run(C.byref(m), C.byref(g), C.byref(od), C.byref(e), supersteps, chunk,
+                                                stream), 'tsg_engine_run')
+                    cnt = self.counters.cpu()
                 supersteps += chunk
-                cnt = self.counters.cpu()
+                chunk_i += 1
                 if int(cnt[3]) >= n_od:
                     break
                 if supersteps > bound:
@@ -367,7 +380,10 @@ class AStarEngine(object):
         if int(cnt[6]) != 0:
             raise RuntimeError('A* engine hit a workspace cap (node/heap/exp capacity)')
         self.last_stats = {'supersteps': supersteps, 'expansions': int(cnt[4]), 'model_evals': int(cnt[5]),
-                           'n_od': n_od}
+                           'n_od': n_od, 'items': int(cnt[7]),
+                           'chain_sum': int(cnt[8:10].view(torch.int64)[0]),
+                           'cand_sum': int(cnt[10:12].view(torch.int64)[0]),
+                           'prof_ms': list(prof_ms), 'prof_launches': list(prof_n), 'prof_items': prof_items}
         res = {'rid': out_rid, 'time': out_time, 'len': out_len, 'status': out_status, 'steps': out_steps}
         if poplog_cap > 0:
             res.update({'poplog_rid': pl_rid, 'poplog_prio': pl_prio, 'poplog_n': pl_n})

@@ -58,7 +58,7 @@ class Searcher(object):
     # -- batched entry (new) ---------------------------------------------------------------------
     @torch.no_grad()
     def generate(self, gen_model, start_rids, start_times, des_rids, default_lens, max_step=500, prefixes=None,
-                 allow_label=None, slots=None, lmax=256, poplog_cap=0, return_device=False):
+                 allow_label=None, slots=None, lmax=256, poplog_cap=0, return_device=False, profile_every=0):
         """Road-level A* for many OD pairs.
 
         start_rids/start_times/des_rids/default_lens: int arrays of length n (prefix = one element), or pass
@@ -86,7 +86,8 @@ class Searcher(object):
             slots = _auto_slots(tables, self.graph(), ms_cap, max_prefix, n_od, self.device)
         eng = self._engine(gen_model, int(slots), ms_cap, max_prefix, lmax)
         res = eng.run(prefix_ptr, prefix_rid, prefix_time, des, np.asarray(default_lens, dtype=np.int32), ms,
-                      allow_label=allow_label, poplog_cap=poplog_cap, return_device=return_device)
+                      allow_label=allow_label, poplog_cap=poplog_cap, return_device=return_device,
+                      profile_every=profile_every)
         self.last_stats = eng.last_stats
         return res
 

@@ -177,36 +177,43 @@ def csr_from_adjacent_list(adjacent_list, n):
     return indptr, indices
 
 
-def hop_distance(net, origins, dests, unreachable=-1):
-    """BFS hop count from each origin to its destination (number of transitions)."""
+def _bfs_chunk(args):
+    from scipy.sparse import csr_matrix
+    from scipy.sparse.csgraph import shortest_path
+    indptr, indices, n, src, rows, dcol = args
+    graph = csr_matrix((np.ones(len(indices), dtype=np.float32), indices, indptr), shape=(n, n))
+    dist = shortest_path(graph, method='D', directed=True, unweighted=True, indices=src)
+    return dist[rows, dcol]
+
+
+def hop_distance(net, origins, dests, unreachable=-1, chunk=256, workers=1):
+    """BFS hop count from each origin to its destination (number of transitions).
+    `workers` > 1 forks a process pool: call it before the process has touched the GPU."""
     n = net.num_roads
     indptr, indices = csr_from_adjacent_list(net.adjacent_list, n)
     origins = np.asarray(origins, dtype=np.int64)
     dests = np.asarray(dests, dtype=np.int64)
     out = np.full(len(origins), unreachable, dtype=np.int64)
-    by_origin = {}
-    for k, o in enumerate(origins):
-        by_origin.setdefault(int(o), []).append(k)
-    for o, ks in by_origin.items():
-        dist = np.full(n, -1, dtype=np.int64)
-        dist[o] = 0
-        frontier = np.array([o], dtype=np.int64)
-        want = set(int(dests[k]) for k in ks)
-        d = 0
-        while len(frontier) and want:
-            d += 1
-            nxt = np.concatenate([indices[indptr[u]:indptr[u + 1]] for u in frontier]) if len(frontier) else frontier
-            nxt = np.unique(nxt)
-            nxt = nxt[dist[nxt] < 0]
-            dist[nxt] = d
-            want -= set(nxt.tolist())
-            frontier = nxt
-        for k in ks:
-            out[k] = dist[dests[k]] if dist[dests[k]] >= 0 else unreachable
+    uniq, inv = np.unique(origins, return_inverse=True)
+    order = np.argsort(inv, kind='stable')
+    bounds = np.searchsorted(inv[order], np.arange(0, len(uniq) + chunk, chunk))
+    jobs, sels = [], []
+    for k, c0 in enumerate(range(0, len(uniq), chunk)):
+        sel = order[bounds[k]:bounds[k + 1]]
+        sels.append(sel)
+        jobs.append((indptr, indices, n, uniq[c0:c0 + chunk], inv[sel] - c0, dests[sel]))
+    if workers > 1 and len(jobs) > 1:
+        import multiprocessing as mp
+        with mp.get_context('fork').Pool(min(workers, len(jobs))) as pool:
+            results = pool.map(_bfs_chunk, jobs)
+    else:
+        results = [_bfs_chunk(j) for j in jobs]
+    for sel, d in zip(sels, results):
+        out[sel] = np.where(np.isfinite(d), d, unreachable).astype(np.int64)
     return out
 
 
-def make_od_pairs(net, n_od, seed=2, default_len='hops', unreachable_len=20):
+def make_od_pairs(net, n_od, seed=2, default_len='hops', unreachable_len=20, workers=1):
     """OD pairs uniform over segments (o != d), start time codes U{0..2879}.
 
     default_len: 'hops' = BFS hop distance + 1 (exact, slow for many ODs), or an int constant.
@@ -219,7 +226,7 @@ def make_od_pairs(net, n_od, seed=2, default_len='hops', unreachable_len=20):
     d = np.where(d >= o, d + 1, d)
     t = rng.randint(0, 2880, size=n_od)
     if default_len == 'hops':
-        hops = hop_distance(net, o, d)
+        hops = hop_distance(net, o, d, workers=workers)
         dl = np.where(hops >= 0, hops + 1, unreachable_len)
     else:
         dl = np.full(n_od, int(default_len))
