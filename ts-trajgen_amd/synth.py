@@ -55,8 +55,8 @@ def _finish(n, succ, mid_lon, mid_lat, length, grid, seed, meta):
     adj_mx = sp.coo_matrix((np.ones(len(rows), dtype=np.float32), (rows, cols)), shape=(n + 1, n + 1))
     feats = np.empty((n, 12), dtype=np.float32)
     feats[:, :10] = rng.rand(n, 10).astype(np.float32)
-    feats[:, 10] = np.floor((mid_lon - LON0) / CELL + 1e-9)
-    feats[:, 11] = np.floor((mid_lat - LAT0) / CELL + 1e-9)
+    feats[:, 10] = np.clip(np.floor((mid_lon - LON0) / CELL + 1e-9), 0, grid)
+    feats[:, 11] = np.clip(np.floor((mid_lat - LAT0) / CELL + 1e-9), 0, grid)
     meta = dict(meta)
     meta['num_edges'] = int(len(rows))
     return RoadNetwork(n, adjacent_list, rid_gps, road_length, rtd, adj_mx, feats, grid + 1, grid + 1, meta)
