@@ -178,7 +178,8 @@ typedef struct tsg_graph {
   int32_t max_degree;
   const int32_t* indptr;  /* [n_roads+1] successors CSR, order of adjacent_list preserved */
   const int32_t* indices; /* [E] */
-  const double* lonlat;   /* [n_roads][2] (lon, lat) degrees, road_center_gps */
+  const double* geo;      /* [n_roads][4] {lon_deg, lat_deg, sinU, cosU}, U = atan((1-f) tan(lat)): road_center_gps
+                             with the reduced-latitude terms of the WGS-84 inverse geodesic precomputed (fp64) */
   const int32_t* cost;    /* [24][n_roads] seconds: rtd if != 1 else int(round(len/8.334)) (search.py:376-381) */
   const int32_t* label;   /* [n_roads] region label per road, or NULL (no in-region gating) */
 } tsg_graph;
@@ -215,6 +216,8 @@ typedef struct tsg_engine {
   uint32_t* table;      size_t table_bytes;       /* [B][n_roads] rid -> (generation<<20 | node+1), zeroed by caller */
   int32_t* nodes;       size_t nodes_bytes;       /* [B][node_cap][8] int32 */
   int32_t* exp_meta;    size_t exp_meta_bytes;    /* [B][exp_cap][4] {parent, rid, tcode, depth} */
+  int32_t* exp_up;      size_t exp_up_bytes;      /* [B][exp_cap][up_levels]: 2^k-th ancestor slot (binary lifting) */
+  int32_t up_levels;    int32_t reserved0;        /* 7 <= up_levels <= 24, 2^up_levels >= exp_cap */
   float* h[TSG_MAX_LAYERS];                       /* [B*exp_cap][Hp] per layer */
   float* c[TSG_MAX_LAYERS];
   size_t state_bytes;                             /* bytes of EACH h[l] / c[l] */

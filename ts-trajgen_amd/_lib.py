@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libtsg.so')
+LIB_PATH = os.environ.get('TSG_LIB_OVERRIDE') or os.path.join(_HERE, 'csrc', 'libtsg.so')  # override: ablation builds only
 
 TSG_MAX_LAYERS = 4
 TSG_MAX_DEGREE = 64
@@ -49,7 +49,7 @@ class ScoreBatch(C.Structure):
 
 
 class Graph(C.Structure):
-    _fields_ = [('n_roads', _i32), ('max_degree', _i32), ('indptr', _p), ('indices', _p), ('lonlat', _p),
+    _fields_ = [('n_roads', _i32), ('max_degree', _i32), ('indptr', _p), ('indices', _p), ('geo', _p),
                 ('cost', _p), ('label', _p)]
 
 
@@ -64,7 +64,8 @@ class Engine(C.Structure):
     _fields_ = [('slots', _i32), ('exp_cap', _i32), ('node_cap', _i32), ('heap_cap', _i32),
                 ('slot_state', _p), ('slot_state_bytes', _sz), ('heap', _p), ('heap_bytes', _sz),
                 ('table', _p), ('table_bytes', _sz), ('nodes', _p), ('nodes_bytes', _sz),
-                ('exp_meta', _p), ('exp_meta_bytes', _sz),
+                ('exp_meta', _p), ('exp_meta_bytes', _sz), ('exp_up', _p), ('exp_up_bytes', _sz),
+                ('up_levels', _i32), ('reserved0', _i32),
                 ('h', _p * TSG_MAX_LAYERS), ('c', _p * TSG_MAX_LAYERS), ('state_bytes', _sz),
                 ('items', _p), ('items_bytes', _sz), ('cand_lp', _p), ('cand_lp_bytes', _sz),
                 ('counters', _p), ('counters_bytes', _sz)]

@@ -3,20 +3,22 @@
 #include "tsg_common.h"
 
 // WGS-84 inverse geodesic (Vincenty), fp64, metres.  Same iteration as oracle/geodesic.py; stands
-// in for geopy.distance.distance(...) at search.py:355-356.
-__device__ inline double tsg_dev_geodesic_m(double lat1, double lon1, double lat2, double lon2) {
+// in for geopy.distance.distance(...) at search.py:355-356.  The per-road reduced-latitude terms
+// sinU = sin(atan((1-f) tan(lat))), cosU are precomputed on the host (tsg_graph.geo rows are
+// {lon_deg, lat_deg, sinU, cosU}).
+__device__ inline double tsg_dev_geodesic_m(const double* __restrict__ p1, const double* __restrict__ p2) {
   const double a = 6378137.0;
   const double f = 1.0 / 298.257223563;
   const double b = a * (1.0 - f);
+  const double lon1 = p1[0], lat1 = p1[1], sinU1 = p1[2], cosU1 = p1[3];
+  const double lon2 = p2[0], lat2 = p2[1], sinU2 = p2[2], cosU2 = p2[3];
   if (lat1 == lat2 && lon1 == lon2) return 0.0;
   const double rad = 3.14159265358979323846 / 180.0;
-  const double U1 = atan((1.0 - f) * tan(lat1 * rad));
-  const double U2 = atan((1.0 - f) * tan(lat2 * rad));
   const double L = (lon2 - lon1) * rad;
-  const double sinU1 = sin(U1), cosU1 = cos(U1), sinU2 = sin(U2), cosU2 = cos(U2);
   double lam = L, sin_sigma = 0.0, cos_sigma = 0.0, sigma = 0.0, cos_sq_alpha = 0.0, cos2sm = 0.0;
   for (int it = 0; it < 20; ++it) {
-    const double sin_lam = sin(lam), cos_lam = cos(lam);
+    double sin_lam, cos_lam;
+    sincos(lam, &sin_lam, &cos_lam);
     const double t1 = cosU2 * sin_lam;
     const double t2 = cosU1 * sinU2 - sinU1 * cosU2 * cos_lam;
     sin_sigma = sqrt(t1 * t1 + t2 * t2);
@@ -45,54 +47,118 @@ __device__ inline double tsg_dev_geodesic_m(double lat1, double lon1, double lat
 
 #define TSG_MAXJ 8  // hp <= 512 -> <= 8 values per lane
 
-// Online-softmax attention state of one wave: lane owns elements lane + 64 j of the pooled vector.
+// A state row (hp floats) spread over the wave.  JT = compile-time register count per lane.
+// hp == 256 (JT == 4, J == 4): lane owns elements 4*lane .. 4*lane+3 (one dwordx4 per row);
+// otherwise lane owns elements lane + 64*j.  Every vector that meets in a dot product uses the same map.
+template <int JT>
+__device__ __forceinline__ void load_row(const float* __restrict__ row, float out[JT], int J, int lane) {
+  if (JT == 4 && J == 4) {
+    const float4 v = *reinterpret_cast<const float4*>(row + 4 * lane);
+    out[0] = v.x;
+    out[1] = v.y;
+    out[2] = v.z;
+    out[3] = v.w;
+  } else {
+#pragma unroll
+    for (int j = 0; j < JT; ++j) out[j] = (j < J) ? row[lane + 64 * j] : 0.0f;
+  }
+}
+
+// Online-softmax attention state of one wave (IntraAttention.forward, function_g_fc.py:31-35).
+template <int JT>
 struct AttnAcc {
   float m, l;
-  float v[TSG_MAXJ];
+  float v[JT];
 };
 
-__device__ __forceinline__ void attn_init(AttnAcc& s) {
+template <int JT>
+__device__ __forceinline__ void attn_init(AttnAcc<JT>& s) {
   s.m = -INFINITY;
   s.l = 0.0f;
 #pragma unroll
-  for (int j = 0; j < TSG_MAXJ; ++j) s.v[j] = 0.0f;
+  for (int j = 0; j < JT; ++j) s.v[j] = 0.0f;
 }
 
-// Fold one key row (already in registers) into the running softmax(keys . q)-weighted sum
-// (IntraAttention.forward, function_g_fc.py:31-35).
-__device__ __forceinline__ void attn_fold(AttnAcc& s, const float key[TSG_MAXJ], const float q[TSG_MAXJ], int J) {
-  float part = 0.0f;
+// Fold up to 4 key rows at once: 4 independent dot products and butterfly reductions in flight.
+// rows[u] == nullptr marks an absent row.
+template <int JT>
+__device__ __forceinline__ void attn_fold4(AttnAcc<JT>& s, const float* const rows[4], const float q[JT], int J,
+                                           int lane) {
+  float key[4][JT];
+  float part[4];
 #pragma unroll
-  for (int j = 0; j < TSG_MAXJ; ++j)
-    if (j < J) part += key[j] * q[j];
-  const float sc = tsg_wave_sum(part);
-  const float mn = fmaxf(s.m, sc);
+  for (int u = 0; u < 4; ++u) {
+    if (rows[u]) {
+      load_row<JT>(rows[u], key[u], J, lane);
+    } else {
+#pragma unroll
+      for (int j = 0; j < JT; ++j) key[u][j] = 0.0f;
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    part[u] = 0.0f;
+#pragma unroll
+    for (int j = 0; j < JT; ++j) part[u] += key[u][j] * q[j];
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) part[u] += __shfl_xor(part[u], o, TSG_WAVE);
+  }
+  float mn = s.m;
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+    if (rows[u]) mn = fmaxf(mn, part[u]);
   const float scale = expf(s.m - mn);  // exp(-inf) = 0 on the first fold
-  const float w = expf(sc - mn);
-  s.l = s.l * scale + w;
+  float w[4];
+  float wsum = 0.0f;
 #pragma unroll
-  for (int j = 0; j < TSG_MAXJ; ++j)
-    if (j < J) s.v[j] = s.v[j] * scale + w * key[j];
+  for (int u = 0; u < 4; ++u) {
+    w[u] = rows[u] ? expf(part[u] - mn) : 0.0f;
+    wsum += w[u];
+  }
+  s.l = s.l * scale + wsum;
+#pragma unroll
+  for (int j = 0; j < JT; ++j) {
+    float a = s.v[j] * scale;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) a += w[u] * key[u][j];
+    s.v[j] = a;
+  }
   s.m = mn;
 }
 
-// Score up to 64 candidates of one row.  Lane i < ncand returns log-free probability f_i of
+// Score up to 64 candidates of one row.  Lane i < ncand returns the probability f_i of
 // softmax((1-w1) softmax(G) + w1 softmax(H))  (generator_v4.py:46-54,71-72); also the two inner
-// softmaxes through pg/ph.  `pooled` = attention-pooled hidden (lane owns lane + 64 j).
-__device__ __forceinline__ float score_row(const tsg_model& m, const float pooled[TSG_MAXJ], int J, int lane,
-                                           int ncand, int my_cand, float my_dis, int des, float* pg, float* ph) {
+// softmaxes through pg/ph.  `pooled` = attention-pooled hidden in the load_row lane map.
+template <int JT>
+__device__ __forceinline__ float score_row(const tsg_model& m, const float pooled[JT], int J, int lane, int ncand,
+                                           int my_cand, float my_dis, int des, float* pg, float* ph) {
   const int hp = m.hp;
   // G: gathered rows of out_fc (function_g_fc.py:184-186) -- only the ncand rows that are needed
   float g_logit = -INFINITY;
-  for (int c = 0; c < ncand; ++c) {
-    const int cid = __shfl(my_cand, c, TSG_WAVE);
-    const float* w = m.out_w + (size_t)cid * hp;
-    float part = 0.0f;
+  for (int c0 = 0; c0 < ncand; c0 += 4) {
+    float part[4];
+    int cid[4];
 #pragma unroll
-    for (int j = 0; j < TSG_MAXJ; ++j)
-      if (j < J) part += w[lane + 64 * j] * pooled[j];
-    const float tot = tsg_wave_sum(part) + m.out_b[cid];
-    if (lane == c) g_logit = tot;
+    for (int u = 0; u < 4; ++u) {
+      const int c = c0 + u < ncand ? c0 + u : ncand - 1;
+      cid[u] = __shfl(my_cand, c, TSG_WAVE);
+      float w[JT];
+      load_row<JT>(m.out_w + (size_t)cid[u] * hp, w, J, lane);
+      part[u] = 0.0f;
+#pragma unroll
+      for (int j = 0; j < JT; ++j) part[u] += w[j] * pooled[j];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) part[u] += __shfl_xor(part[u], o, TSG_WAVE);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (lane == c0 + u && c0 + u < ncand) g_logit = part[u] + m.out_b[cid[u]];
   }
   // H: factored emb_fc + dis_fc + out_fc (distance_gat_fc.py:129-133)
   float h_logit = -INFINITY;

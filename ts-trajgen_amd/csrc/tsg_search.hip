@@ -4,6 +4,10 @@
 
 #include "tsg_device.h"
 
+#ifndef TSG_ABLATE
+#define TSG_ABLATE 0  // timing-only ablation builds (tools/ablate.sh); 0 in the shipped library
+#endif
+
 int tsg_launch_lstm_layer(const tsg_model* m, int layer, int max_rows, const int32_t* n_rows_dev, int n_rows_host,
                           const int64_t* prev_idx, const int64_t* out_idx, const int32_t* rid, const int32_t* tcode,
                           const int32_t* items, int exp_cap, const float* h_below, float* h, float* c,
@@ -12,6 +16,7 @@ int tsg_launch_lstm_layer(const tsg_model* m, int layer, int max_rows, const int
 // =====================================================================================
 // explicit-row scoring: GeneratorV4.predict (generator_v4.py:56-72) for (prefix, candidates, dis) rows
 // =====================================================================================
+template <int JT>
 __global__ __launch_bounds__(256) void score_batch_kernel(tsg_model m, tsg_score_batch sb) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
@@ -20,31 +25,34 @@ __global__ __launch_bounds__(256) void score_batch_kernel(tsg_model m, tsg_score
   const int c0 = sb.chain_ptr[row], c1 = sb.chain_ptr[row + 1];
   const int k0 = sb.cand_ptr[row], ncand = sb.cand_ptr[row + 1] - k0;
   if (c1 <= c0 || ncand <= 0) return;
-  float q[TSG_MAXJ], key[TSG_MAXJ];
-  const float* qrow = sb.h_top + (size_t)sb.chain[c1 - 1] * hp;
-#pragma unroll
-  for (int j = 0; j < TSG_MAXJ; ++j) q[j] = (j < J) ? qrow[lane + 64 * j] : 0.0f;
-  AttnAcc acc;
+  float q[JT];
+  load_row<JT>(sb.h_top + (size_t)sb.chain[c1 - 1] * hp, q, J, lane);
+  AttnAcc<JT> acc;
   attn_init(acc);
-  for (int i = c1 - 1; i >= c0; --i) {
-    const float* kr = sb.h_top + (size_t)sb.chain[i] * hp;
+  for (int i = c1 - 1; i >= c0; i -= 4) {
+    const float* rows[4];
 #pragma unroll
-    for (int j = 0; j < TSG_MAXJ; ++j) key[j] = (j < J) ? kr[lane + 64 * j] : 0.0f;
-    attn_fold(acc, key, q, J);
+    for (int u = 0; u < 4; ++u) rows[u] = (i - u >= c0) ? sb.h_top + (size_t)sb.chain[i - u] * hp : nullptr;
+    attn_fold4<JT>(acc, rows, q, J, lane);
   }
-  float pooled[TSG_MAXJ];
+  float pooled[JT];
   const float inv = 1.0f / acc.l;
 #pragma unroll
-  for (int j = 0; j < TSG_MAXJ; ++j) pooled[j] = acc.v[j] * inv;
+  for (int j = 0; j < JT; ++j) pooled[j] = acc.v[j] * inv;
   const int my_cand = lane < ncand ? sb.cand[k0 + lane] : 0;
   const float my_dis = lane < ncand ? sb.dis[k0 + lane] : 0.0f;
   float pg, ph;
-  const float f = score_row(m, pooled, J, lane, ncand, my_cand, my_dis, sb.des[row], &pg, &ph);
+  const float f = score_row<JT>(m, pooled, J, lane, ncand, my_cand, my_dis, sb.des[row], &pg, &ph);
   if (lane < ncand) {
     sb.prob[k0 + lane] = f;
     if (sb.prob_g) sb.prob_g[k0 + lane] = pg;
     if (sb.prob_h) sb.prob_h[k0 + lane] = ph;
   }
+}
+
+static inline int jt_for(int hp) {
+  const int J = hp / 64;
+  return J <= 1 ? 1 : J <= 2 ? 2 : J <= 4 ? 4 : 8;
 }
 
 extern "C" int tsg_score_candidates(const tsg_model* m, const tsg_score_batch* b, void* stream) {
@@ -55,7 +63,14 @@ extern "C" int tsg_score_candidates(const tsg_model* m, const tsg_score_batch* b
     return TSG_E_INVALID;
   if (!m->out_w || !m->out_b || !m->pfrom || !m->pto || !m->hparams) return TSG_E_INVALID;
   if (b->n_rows == 0) return 0;
-  hipLaunchKernelGGL(score_batch_kernel, dim3(tsg_cdiv(b->n_rows, 4)), dim3(256), 0, (hipStream_t)stream, *m, *b);
+  const dim3 grid(tsg_cdiv(b->n_rows, 4)), blk(256);
+  hipStream_t s = (hipStream_t)stream;
+  switch (jt_for(m->hp)) {
+    case 1: hipLaunchKernelGGL(score_batch_kernel<1>, grid, blk, 0, s, *m, *b); break;
+    case 2: hipLaunchKernelGGL(score_batch_kernel<2>, grid, blk, 0, s, *m, *b); break;
+    case 4: hipLaunchKernelGGL(score_batch_kernel<4>, grid, blk, 0, s, *m, *b); break;
+    default: hipLaunchKernelGGL(score_batch_kernel<8>, grid, blk, 0, s, *m, *b); break;
+  }
   TSG_LAUNCH_CHECK();
   return 0;
 }
@@ -69,6 +84,11 @@ struct EngineDev {
   tsg_od_batch od;
 };
 
+// Ancestors are found through a binary-lifting table: up[e][k] = the 2^k-th ancestor of expanded
+// slot e (or -1).  A wave first writes the row of its own slot (one dependent load per level), then
+// lane t resolves the t-th ancestor in <= 6 dependent loads, so the key rows of the attention are
+// fetched as independent, fully coalesced row loads instead of a pointer chase.
+template <int JT>
 __global__ __launch_bounds__(256) void score_frontier_kernel(tsg_model m, EngineDev D, int superstep) {
   const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
@@ -81,46 +101,96 @@ __global__ __launch_bounds__(256) void score_frontier_kernel(tsg_model m, Engine
   if (idx >= n_items) return;
   const int32_t* it = D.e.items + (size_t)idx * IT_WORDS;
   const int ncand = it[IT_NCAND];
+  const int b = it[IT_SLOT], e = it[IT_EXP];
+  const int LV = D.e.up_levels;
+  int32_t* up = D.e.exp_up + (size_t)b * D.e.exp_cap * LV;
+  // up[e][*]: every lane computes the same chain (wave-uniform addresses), lane 0 stores.  The first 7
+  // levels stay in registers: this wave must not read back what it has just stored.
+  int mine[7];
+  {
+    int a = it[IT_PARENT];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+      mine[k] = a;
+      if (lane == 0) up[(size_t)e * LV + k] = a;
+      a = (a >= 0) ? up[(size_t)a * LV + k] : -1;
+    }
+    for (int k = 7; k < LV; ++k) {
+      if (lane == 0) up[(size_t)e * LV + k] = a;
+      a = (a >= 0) ? up[(size_t)a * LV + k] : -1;
+    }
+  }
   if (ncand < 2) return;  // warm-up rows and single-successor expansions need no model call (search.py:302)
-  const int b = it[IT_SLOT], e = it[IT_EXP], rid = it[IT_RID], des = it[IT_DES];
+  const int rid = it[IT_RID], des = it[IT_DES];
   const float lp_parent = __int_as_float(it[IT_LP]);
   const int hp = m.hp, J = hp / 64;
   const float* htop = D.e.h[m.n_layers - 1] + (size_t)b * D.e.exp_cap * hp;
   const int32_t* em = D.e.exp_meta + (size_t)b * D.e.exp_cap * EM_WORDS;
-  float q[TSG_MAXJ], key[TSG_MAXJ];
-#pragma unroll
-  for (int j = 0; j < TSG_MAXJ; ++j) q[j] = (j < J) ? htop[(size_t)e * hp + lane + 64 * j] : 0.0f;
-  AttnAcc acc;
+  const int depth = em[(size_t)e * EM_WORDS + EM_DEPTH];  // = number of rows on the ancestor chain incl. e
+  float q[JT];
+  load_row<JT>(htop + (size_t)e * hp, q, J, lane);
+  AttnAcc<JT> acc;
   attn_init(acc);
-  int cur = e;
-  int chain_len = 0;
-  while (cur >= 0) {  // ancestor chain: parent pointers of closed (immutable) nodes
-    ++chain_len;
-    const int nxt = em[(size_t)cur * EM_WORDS + EM_PARENT];
-    const float* kr = htop + (size_t)cur * hp;
+  int anchor = e;  // the (64 * chunk)-th ancestor
+  for (int base = 0; base < depth; base += 64) {
+    const int n = depth - base < 64 ? depth - base : 64;
+    // lane t: the t-th ancestor of `anchor` (distance t = lane), -1 beyond the chain
+    int cur = lane < n ? anchor : -1;
 #pragma unroll
-    for (int j = 0; j < TSG_MAXJ; ++j) key[j] = (j < J) ? kr[lane + 64 * j] : 0.0f;
-    attn_fold(acc, key, q, J);
-    cur = nxt;
+    for (int k = 0; k < 6; ++k) {
+      const bool hop = ((lane >> k) & 1) && cur >= 0;
+      if (hop) cur = (cur == e) ? mine[k] : up[(size_t)cur * LV + k];
+    }
+    for (int i = 0; i < n; i += 4) {
+      const float* rows[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int src_lane = i + u < n ? i + u : n - 1;
+        const int id = __shfl(cur, src_lane, TSG_WAVE);
+        rows[u] = (i + u < n) ? htop + (size_t)id * hp : nullptr;
+      }
+#if TSG_ABLATE == 2
+      if (i > 0) continue;
+#endif
+      attn_fold4<JT>(acc, rows, q, J, lane);
+    }
+    if (base + 64 < depth) anchor = (anchor == e) ? mine[6] : up[(size_t)anchor * LV + 6];
   }
-  float pooled[TSG_MAXJ];
+  float pooled[JT];
   const float inv = 1.0f / acc.l;
 #pragma unroll
-  for (int j = 0; j < TSG_MAXJ; ++j) pooled[j] = acc.v[j] * inv;
+  for (int j = 0; j < JT; ++j) pooled[j] = acc.v[j] * inv;
   int my_cand = 0;
   float my_dis = 0.0f;
   if (lane < ncand) {
     my_cand = D.g.indices[D.g.indptr[rid] + lane];
-    const double dlon = D.g.lonlat[2 * (size_t)des], dlat = D.g.lonlat[2 * (size_t)des + 1];
-    const double clon = D.g.lonlat[2 * (size_t)my_cand], clat = D.g.lonlat[2 * (size_t)my_cand + 1];
-    my_dis = (float)(tsg_dev_geodesic_m(dlat, dlon, clat, clon) / 1000.0 * 10.0);  // search.py:355-356
+#if TSG_ABLATE == 1
+    const double dm = 1234.0 + my_cand;
+#else
+    const double dm = tsg_dev_geodesic_m(D.g.geo + 4 * (size_t)des, D.g.geo + 4 * (size_t)my_cand);
+#endif
+    my_dis = (float)(dm / 1000.0 * 10.0);  // search.py:355-356
   }
-  const float f = score_row(m, pooled, J, lane, ncand, my_cand, my_dis, des, nullptr, nullptr);
+#if TSG_ABLATE == 3
+  const float f = 1.0f / ncand + pooled[0] * 1e-9f + my_dis * 1e-9f;
+#else
+  const float f = score_row<JT>(m, pooled, J, lane, ncand, my_cand, my_dis, des, nullptr, nullptr);
+#endif
   if (lane < ncand) D.e.cand_lp[(size_t)b * D.g.max_degree + lane] = logf(f) + lp_parent;  // search.py:370-373
   if (lane == 0) {
     atomicAdd(&counters[CT_MODEL_EVALS], 1);
-    atomicAdd(reinterpret_cast<unsigned long long*>(&counters[CT_CHAIN_SUM]), (unsigned long long)chain_len);
+    atomicAdd(reinterpret_cast<unsigned long long*>(&counters[CT_CHAIN_SUM]), (unsigned long long)depth);
     atomicAdd(reinterpret_cast<unsigned long long*>(&counters[CT_CAND_SUM]), (unsigned long long)ncand);
+  }
+}
+
+static void launch_score_frontier(const tsg_model* m, const EngineDev& D, int superstep, hipStream_t s) {
+  const dim3 grid(tsg_cdiv(D.e.slots, 4)), blk(256);
+  switch (jt_for(m->hp)) {
+    case 1: hipLaunchKernelGGL(score_frontier_kernel<1>, grid, blk, 0, s, *m, D, superstep); break;
+    case 2: hipLaunchKernelGGL(score_frontier_kernel<2>, grid, blk, 0, s, *m, D, superstep); break;
+    case 4: hipLaunchKernelGGL(score_frontier_kernel<4>, grid, blk, 0, s, *m, D, superstep); break;
+    default: hipLaunchKernelGGL(score_frontier_kernel<8>, grid, blk, 0, s, *m, D, superstep); break;
   }
 }
 
@@ -513,7 +583,10 @@ static int check_engine(const tsg_model* m, const tsg_graph* g, const tsg_od_bat
     if (m->hp <= 0 || (m->hp % 64) != 0 || m->hp > 512) return TSG_E_INVALID;
     if (m->n_layers < 1 || m->n_layers > TSG_MAX_LAYERS) return TSG_E_INVALID;
     if (m->n_roads < g->n_roads) return TSG_E_INVALID;
-    if (!g->lonlat) return TSG_E_INVALID;
+    if (!g->geo) return TSG_E_INVALID;
+    if (e->up_levels < 7 || e->up_levels > 24) return TSG_E_INVALID;
+    if ((1L << e->up_levels) < e->exp_cap) return TSG_E_INVALID;
+    if (!e->exp_up || e->exp_up_bytes < B * e->exp_cap * (size_t)e->up_levels * 4) return TSG_E_TOO_SMALL;
     for (int l = 0; l < m->n_layers; ++l)
       if (!e->h[l] || !e->c[l] || e->state_bytes < B * e->exp_cap * (size_t)m->hp * 4) return TSG_E_TOO_SMALL;
   }
@@ -560,8 +633,7 @@ extern "C" int tsg_score_frontier(const tsg_model* m, const tsg_graph* g, const 
   D.e = *e;
   D.g = *g;
   D.od = tsg_od_batch{};
-  hipLaunchKernelGGL(score_frontier_kernel, dim3(tsg_cdiv(e->slots, 4)), dim3(256), 0, (hipStream_t)stream, *m, D,
-                     superstep);
+  launch_score_frontier(m, D, superstep, (hipStream_t)stream);
   TSG_LAUNCH_CHECK();
   return 0;
 }
@@ -576,7 +648,7 @@ extern "C" int tsg_engine_run(const tsg_model* m, const tsg_graph* g, const tsg_
   D.e = *e;
   D.g = *g;
   D.od = *od;
-  const dim3 fgrid(tsg_cdiv(e->slots, 64)), sgrid(tsg_cdiv(e->slots, 4));
+  const dim3 fgrid(tsg_cdiv(e->slots, 64));
   for (int k = 0; k < n_supersteps; ++k) {
     const int ss = first_superstep + k;
     hipLaunchKernelGGL(frontier_kernel, fgrid, dim3(64), 0, s, D, ss);
@@ -587,7 +659,7 @@ extern "C" int tsg_engine_run(const tsg_model* m, const tsg_graph* g, const tsg_
                                  l > 0 ? e->h[l - 1] : nullptr, e->h[l], e->c[l], s);
       if (rc) return rc;
     }
-    hipLaunchKernelGGL(score_frontier_kernel, sgrid, dim3(256), 0, s, *m, D, ss);
+    launch_score_frontier(m, D, ss, s);
     TSG_LAUNCH_CHECK();
   }
   return 0;
@@ -617,7 +689,7 @@ extern "C" int tsg_engine_run_profiled(const tsg_model* m, const tsg_graph* g, c
       delete[] ev;
       return TSG_E_INVALID;
     }
-  const dim3 fgrid(tsg_cdiv(e->slots, 64)), sgrid(tsg_cdiv(e->slots, 4));
+  const dim3 fgrid(tsg_cdiv(e->slots, 64));
   int q = 0;
   rc = 0;
   for (int k = 0; k < n_supersteps && rc == 0; ++k) {
@@ -633,7 +705,7 @@ extern "C" int tsg_engine_run_profiled(const tsg_model* m, const tsg_graph* g, c
       (void)hipEventRecord(ev[q++], s);
     }
     (void)hipEventRecord(ev[q++], s);
-    hipLaunchKernelGGL(score_frontier_kernel, sgrid, dim3(256), 0, s, *m, D, ss);
+    launch_score_frontier(m, D, ss, s);
     (void)hipEventRecord(ev[q++], s);
   }
   hipError_t he = hipStreamSynchronize(s);

@@ -220,7 +220,10 @@ class GraphTables(object):
         dev = self.device
         self.indptr = torch.from_numpy(indptr).to(dev)
         self.indices = torch.from_numpy(indices if len(indices) else np.zeros(1, np.int32)).to(dev)
-        self.lonlat = torch.from_numpy(lonlat).to(dev)
+        f = 1.0 / 298.257223563
+        u = np.arctan((1.0 - f) * np.tan(lonlat[:, 1] * (np.pi / 180.0)))
+        geo4 = np.stack([lonlat[:, 0], lonlat[:, 1], np.sin(u), np.cos(u)], axis=1)
+        self.geo = torch.from_numpy(np.ascontiguousarray(geo4)).to(dev)
         self.cost = torch.from_numpy(np.ascontiguousarray(cost)).to(dev)
         self.label = None
         if rid_label is not None:
@@ -237,7 +240,7 @@ class GraphTables(object):
     def _build(self):
         g = _lib.Graph()
         g.n_roads, g.max_degree = self.num_roads, self.max_degree
-        g.indptr, g.indices, g.lonlat = _lib.ptr(self.indptr), _lib.ptr(self.indices), _lib.ptr(self.lonlat)
+        g.indptr, g.indices, g.geo = _lib.ptr(self.indptr), _lib.ptr(self.indices), _lib.ptr(self.geo)
         g.cost, g.label = _lib.ptr(self.cost), _lib.ptr(self.label)
         self.c_graph = g
 
@@ -263,6 +266,8 @@ class AStarEngine(object):
         self.table = torch.zeros((B, n), dtype=i32, device=dev)
         self.nodes = torch.empty((B, self.node_cap, 8), dtype=i32, device=dev)
         self.exp_meta = torch.empty((B, self.exp_cap, 4), dtype=i32, device=dev)
+        self.up_levels = max(7, int(math.ceil(math.log2(max(2, self.exp_cap)))))
+        self.exp_up = torch.empty((B, self.exp_cap, self.up_levels), dtype=i32, device=dev)
         self.h = [torch.empty((B * self.exp_cap, hp), dtype=f32, device=dev) for _ in range(nl)]
         self.c = [torch.empty((B * self.exp_cap, hp), dtype=f32, device=dev) for _ in range(nl)]
         self.items = torch.empty((B, 8), dtype=i32, device=dev)
@@ -270,7 +275,7 @@ class AStarEngine(object):
         self.counters = torch.zeros(16, dtype=i32, device=dev)
         e = _lib.Engine()
         e.slots, e.exp_cap, e.node_cap, e.heap_cap = B, self.exp_cap, self.node_cap, self.heap_cap
-        for name in ('slot_state', 'heap', 'table', 'nodes', 'exp_meta', 'items', 'cand_lp', 'counters'):
+        for name in ('slot_state', 'heap', 'table', 'nodes', 'exp_meta', 'exp_up', 'items', 'cand_lp', 'counters'):
             t = getattr(self, name)
             setattr(e, name, t.data_ptr())
             setattr(e, name + '_bytes', t.numel() * t.element_size())
@@ -278,6 +283,7 @@ class AStarEngine(object):
             e.h[l] = self.h[l].data_ptr()
             e.c[l] = self.c[l].data_ptr()
         e.state_bytes = self.h[0].numel() * 4
+        e.up_levels = self.up_levels
         self.c_engine = e
         self.last_stats = {}
 
@@ -287,7 +293,7 @@ class AStarEngine(object):
         node_cap = min(graph.num_roads, 1 + max_step * graph.max_degree) + 1
         heap_cap = 1 + max_step * graph.max_degree
         return (2 * tables.n_layers * exp_cap * tables.hp * 4 + heap_cap * 8 + graph.num_roads * 4
-                + node_cap * 32 + exp_cap * 16 + 32 * 4 + 32 + graph.max_degree * 4)
+                + node_cap * 32 + exp_cap * (16 + 4 * 14) + 32 * 4 + 32 + graph.max_degree * 4)
 
     @torch.no_grad()
     def run(self, prefix_ptr, prefix_rid, prefix_time, des, default_len, max_step, allow_label=None,
