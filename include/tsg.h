@@ -224,9 +224,10 @@ typedef struct tsg_engine {
   int32_t* items;       size_t items_bytes;       /* [B][8] work items of the current superstep */
   float* cand_lp;       size_t cand_lp_bytes;     /* [B][max_degree] */
   int32_t* counters;    size_t counters_bytes;    /* [16]: 0,1 item counters (ping-pong), 2 next OD, 3 finished ODs,
-                                                     4 total expansions, 5 total model evaluations, 6 error flag,
-                                                     7 total work items (LSTM rows), 8-9 (u64) sum of attention chain
-                                                     lengths, 10-11 (u64) sum of scored candidates */
+                                                     4 total expansions, 5 unused, 6 error flag,
+                                                     7 total work items (LSTM rows).  Per-slot statistics live in
+                                                     slot_state words 27..29: model evaluations, scored candidates,
+                                                     attention chain rows */
 } tsg_engine;
 
 /* Reset slot states and counters for a new OD batch (enqueues memsets + an init kernel). */

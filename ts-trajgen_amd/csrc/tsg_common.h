@@ -42,12 +42,11 @@ enum {
   SS_PHASE = 0, SS_OD, SS_STEP, SS_HEAP_N, SS_NODE_N, SS_EXP_N, SS_GEN, SS_WOFF, SS_DES, SS_DEFLEN,
   SS_MAXSTEP, SS_ALLOW, SS_WARM_K, SS_PLEN, SS_CUR_EXP, SS_CUR_RID, SS_CUR_C, SS_CUR_NEXT_TIME,
   SS_CUR_LP, SS_BEST_LP, SS_BEST_PARENT, SS_BEST_RID, SS_BEST_TCODE, SS_HAVE_BEST, SS_NPOP, SS_POFF,
-  SS_CUR_DEPTH, SS_WORDS = 32
+  SS_CUR_DEPTH, SS_ST_EVALS, SS_ST_CAND, SS_ST_CHAIN, SS_WORDS = 32
 };
 enum { PH_IDLE = 0, PH_WARMUP = 1, PH_SEARCH = 2, PH_EXPANDED = 3, PH_DONE = 4 };
 // counters
-enum { CT_ITEMS0 = 0, CT_ITEMS1 = 1, CT_NEXT_OD = 2, CT_FINISHED = 3, CT_EXPANSIONS = 4, CT_MODEL_EVALS = 5, CT_ERROR = 6, CT_ITEMS_TOTAL = 7,
-       CT_CHAIN_SUM = 8 /* u64: words 8,9 */, CT_CAND_SUM = 10 /* u64: words 10,11 */ };
+enum { CT_ITEMS0 = 0, CT_ITEMS1 = 1, CT_NEXT_OD = 2, CT_FINISHED = 3, CT_EXPANSIONS = 4, CT_MODEL_EVALS = 5, CT_ERROR = 6, CT_ITEMS_TOTAL = 7 };
 // work item words ([B][8] int32)
 enum { IT_SLOT = 0, IT_EXP, IT_PARENT, IT_RID, IT_TCODE, IT_NCAND, IT_DES, IT_LP, IT_WORDS = 8 };
 // node record words ([B][node_cap][8] int32)

@@ -177,11 +177,6 @@ __global__ __launch_bounds__(256) void score_frontier_kernel(tsg_model m, Engine
   const float f = score_row<JT>(m, pooled, J, lane, ncand, my_cand, my_dis, des, nullptr, nullptr);
 #endif
   if (lane < ncand) D.e.cand_lp[(size_t)b * D.g.max_degree + lane] = logf(f) + lp_parent;  // search.py:370-373
-  if (lane == 0) {
-    atomicAdd(&counters[CT_MODEL_EVALS], 1);
-    atomicAdd(reinterpret_cast<unsigned long long*>(&counters[CT_CHAIN_SUM]), (unsigned long long)depth);
-    atomicAdd(reinterpret_cast<unsigned long long*>(&counters[CT_CAND_SUM]), (unsigned long long)ncand);
-  }
 }
 
 static void launch_score_frontier(const tsg_model* m, const EngineDev& D, int superstep, hipStream_t s) {
@@ -467,6 +462,11 @@ __global__ __launch_bounds__(64) void frontier_kernel(EngineDev D, int superstep
       S[SS_CUR_NEXT_TIME] = next_time;
       S[SS_CUR_LP] = nd[ND_LP];
       S[SS_CUR_DEPTH] = depth;
+      if (C > 1) {  // per-slot statistics (summed on the host; no same-address atomics on the hot path)
+        S[SS_ST_EVALS] += 1;
+        S[SS_ST_CAND] += C;
+        S[SS_ST_CHAIN] += depth;
+      }
       const int slot = atomicAdd(item_cnt, 1);
       int32_t* it = D.e.items + (size_t)slot * IT_WORDS;
       it[IT_SLOT] = b;

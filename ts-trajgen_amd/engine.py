@@ -385,10 +385,10 @@ class AStarEngine(object):
                                        % (bound, int(cnt[3]), n_od))
         if int(cnt[6]) != 0:
             raise RuntimeError('A* engine hit a workspace cap (node/heap/exp capacity)')
-        self.last_stats = {'supersteps': supersteps, 'expansions': int(cnt[4]), 'model_evals': int(cnt[5]),
+        st = self.slot_state.to(torch.int64).sum(dim=0).cpu()
+        self.last_stats = {'supersteps': supersteps, 'expansions': int(cnt[4]), 'model_evals': int(st[27]),
                            'n_od': n_od, 'items': int(cnt[7]),
-                           'chain_sum': int(cnt[8:10].view(torch.int64)[0]),
-                           'cand_sum': int(cnt[10:12].view(torch.int64)[0]),
+                           'chain_sum': int(st[29]), 'cand_sum': int(st[28]),
                            'prof_ms': list(prof_ms), 'prof_launches': list(prof_n), 'prof_items': prof_items}
         res = {'rid': out_rid, 'time': out_time, 'len': out_len, 'status': out_status, 'steps': out_steps}
         if poplog_cap > 0:
