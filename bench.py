@@ -47,6 +47,7 @@ def parse():
     ap.add_argument('--max-step', type=int, default=5000)
     ap.add_argument('--slots', type=int, default=0, help='searches in flight per GPU (0 = auto)')
     ap.add_argument('--lmax', type=int, default=256)
+    ap.add_argument('--streams', type=int, default=1, help='sub-engines (HIP streams) per GPU sharing the OD queue')
     ap.add_argument('--profile-every', type=int, default=8, help='event-bracket every k-th chunk of supersteps')
     ap.add_argument('--cpu-seconds', type=float, default=20.0, help='CPU baseline budget (0 = skip)')
     return ap.parse_args()
@@ -138,7 +139,7 @@ def main():
     def one_step(o, profile_every=0):
         res = searcher.generate(model, o['start'], o['start_time'], o['des'], o['default_len'],
                                 max_step=args.max_step, slots=slots, lmax=args.lmax, return_device=True,
-                                profile_every=profile_every)
+                                profile_every=profile_every, streams=args.streams)
         if world > 1:   # the single exchange step of the path: collect the padded trajectories (RCCL over xGMI)
             packed = torch.cat([res['rid'], res['time'], res['len'].unsqueeze(1), res['status'].unsqueeze(1)], dim=1)
             gathered = torch.empty((world,) + tuple(packed.shape), dtype=packed.dtype, device=packed.device)
@@ -231,7 +232,7 @@ def main():
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': '%s, %d OD pairs per GPU, BJ model dims (hidden 256, 2-layer LSTM, GAT 5x256), '
                                    'random-init weights, max_step %d' % (net_name, args.ods, args.max_step),
-                       'od_pairs_per_gpu': args.ods, 'slots_in_flight': slots, 'parallelism': 'od-shard x%d' % world},
+                       'od_pairs_per_gpu': args.ods, 'slots_in_flight': slots, 'streams': args.streams, 'parallelism': 'od-shard x%d' % world},
             'expansions_per_s': exp_all / dt, 'expansions_per_od': exp_all / n_done,
             'reached_frac': float((status & 0xff == 1).mean()), 'fallback_frac': float((status & 0xff == 2).mean()),
             'avg_prefix_len_scored': avg_L, 'avg_candidates_scored': avg_C,

@@ -223,6 +223,9 @@ typedef struct tsg_engine {
   size_t state_bytes;                             /* bytes of EACH h[l] / c[l] */
   int32_t* items;       size_t items_bytes;       /* [B][8] work items of the current superstep */
   float* cand_lp;       size_t cand_lp_bytes;     /* [B][max_degree] */
+  int32_t* shared_counters;                       /* [16] words 2,3,4,6 below; == counters for a lone engine.  Several
+                                                     engines (disjoint workspaces, one HIP stream each) that work on
+                                                     the SAME tsg_od_batch share this array: one OD queue */
   int32_t* counters;    size_t counters_bytes;    /* [16]: 0,1 item counters (ping-pong), 2 next OD, 3 finished ODs,
                                                      4 total expansions, 5 unused, 6 error flag,
                                                      7 total work items (LSTM rows).  Per-slot statistics live in
@@ -230,7 +233,8 @@ typedef struct tsg_engine {
                                                      attention chain rows */
 } tsg_engine;
 
-/* Reset slot states and counters for a new OD batch (enqueues memsets + an init kernel). */
+/* Reset slot states, the rid table and `counters` for a new OD batch (enqueues memsets).  The caller zeroes
+ * `shared_counters` itself when it is a separate array. */
 int tsg_engine_reset(const tsg_engine* e, const tsg_graph* g, void* stream);
 
 /* Enqueue `n_supersteps` supersteps.  `first_superstep` is the index of the first one (parity

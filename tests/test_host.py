@@ -45,7 +45,7 @@ def test_struct_sizes_match_header():
     from ts_trajgen_amd import _lib
     assert ctypes.sizeof(_lib.Graph) == 8 + 5 * 8
     assert ctypes.sizeof(_lib.Model) == 16 + (3 + 8 + 5) * 8
-    assert ctypes.sizeof(_lib.Engine) == 16 + 5 * 16 + 16 + 8 + 8 * 8 + 8 + 3 * 16
+    assert ctypes.sizeof(_lib.Engine) == 16 + 5 * 16 + 16 + 8 + 8 * 8 + 8 + 3 * 16 + 8
 
 
 def test_gate_permutation_roundtrip():

@@ -1,0 +1,28 @@
+"""Aggregate a rocprofv3 --pmc CSV (one row per dispatch and counter) into per-kernel averages."""
+import csv
+import glob
+import sys
+from collections import defaultdict
+
+
+def main(paths, out):
+    acc = defaultdict(lambda: defaultdict(float))
+    cnt = defaultdict(lambda: defaultdict(int))
+    for path in paths:
+        for fn in glob.glob(path + '/**/*counter_collection.csv', recursive=True):
+            with open(fn) as f:
+                for row in csv.DictReader(f):
+                    k = row['Kernel_Name'].split('(')[0]
+                    c = row['Counter_Name']
+                    acc[k][c] += float(row['Counter_Value'])
+                    cnt[k][c] += 1
+    with open(out, 'w') as f:
+        f.write('kernel,counter,dispatches,avg_per_dispatch,total\n')
+        for k in sorted(acc):
+            for c in sorted(acc[k]):
+                f.write('%s,%s,%d,%.6g,%.6g\n' % (k, c, cnt[k][c], acc[k][c] / cnt[k][c], acc[k][c]))
+    print(open(out).read())
+
+
+if __name__ == '__main__':
+    main(sys.argv[2:], sys.argv[1])

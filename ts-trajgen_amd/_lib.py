@@ -68,7 +68,7 @@ class Engine(C.Structure):
                 ('up_levels', _i32), ('reserved0', _i32),
                 ('h', _p * TSG_MAX_LAYERS), ('c', _p * TSG_MAX_LAYERS), ('state_bytes', _sz),
                 ('items', _p), ('items_bytes', _sz), ('cand_lp', _p), ('cand_lp_bytes', _sz),
-                ('counters', _p), ('counters_bytes', _sz)]
+                ('shared_counters', _p), ('counters', _p), ('counters_bytes', _sz)]
 
 
 _lib = None

@@ -35,7 +35,9 @@ __device__ __forceinline__ float tsg_wave_max(float v) {
   return v;
 }
 
-__device__ __forceinline__ float tsg_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+// v_exp_f32 / v_rcp_f32 forms (about 1e-7 absolute error, far inside the 1e-4 parity budget)
+__device__ __forceinline__ float tsg_sigmoid(float x) { return __frcp_rn(1.0f + __expf(-x)); }
+__device__ __forceinline__ float tsg_tanh(float x) { return 1.0f - 2.0f * __frcp_rn(1.0f + __expf(2.0f * x)); }
 
 // slot-state word indices (engine.slot_state is [B][32] int32)
 enum {

@@ -11,6 +11,10 @@
 // B tile as [k][128] (lanes read consecutive columns).
 #include "tsg_common.h"
 
+#ifndef TSG_ABLATE
+#define TSG_ABLATE 0  // timing-only ablation builds; 0 in the shipped library
+#endif
+
 #define BM 128
 #define BN 128
 #define BK 32
@@ -123,7 +127,7 @@ struct LstmArgs {
   const float* bias;   // layer >= 1
 };
 
-__global__ __launch_bounds__(256) void lstm_layer_kernel(LstmArgs a) {
+__global__ __launch_bounds__(256, 2) void lstm_layer_kernel(LstmArgs a) {
   __shared__ TileLds t;
   __shared__ long long s_prev[BM];
   __shared__ long long s_out[BM];
@@ -167,14 +171,43 @@ __global__ __launch_bounds__(256) void lstm_layer_kernel(LstmArgs a) {
     s_tc[tid] = tc;
   }
   __syncthreads();
-  tsg_f32x16 acc[4];
-#pragma unroll
-  for (int g = 0; g < 4; ++g)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[g][i] = 0.0f;
   const int K = a.layer == 0 ? hp : 2 * hp;
   const int ldw = 4 * hp;
-  for (int k0 = 0; k0 < K; k0 += BK) {
+  const int u = coltile * 32 + (lane & 31);
+  const int gcol = coltile * BN + (lane & 31);
+  // The additive gate terms (layer 0: xproj[rid] + tproj[tcode]; layer >= 1: bias) and the previous cell
+  // state are fetched now into registers: ~150 independent gathers in flight under the K loop instead of
+  // 16 dependent round trips in the epilogue.
+  tsg_f32x16 acc[4];
+  float addv[4][16];
+  float cprev[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int r = wave * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+    const long long pv = s_prev[r];
+    cprev[i] = a.c[(size_t)(pv >= 0 ? pv : 0) * hp + u];  // unconditional load, masked in the epilogue
+#pragma unroll
+    for (int g = 0; g < 4; ++g) acc[g][i] = 0.0f;
+  }
+  if (a.layer == 0) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int r = wave * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+      const float* xp = a.xproj + (size_t)s_rid[r] * ldw + gcol;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) addv[g][i] = xp[g * 32];
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) addv[g][i] = a.bias[gcol + g * 32];
+  }
+  // software pipeline: the global loads of k-tile t+1 are issued before the MFMAs of tile t and land in
+  // registers while the matrix cores work; they are written to LDS after the tile's last read.
+  float4 ra[4], rb[4];
+  bool amask[4];
+  auto gload = [&](int k0) {
     const bool below = (a.layer > 0) && (k0 < hp);
     const int kcol = below ? k0 : (a.layer > 0 ? k0 - hp : k0);
     const float* src = below ? a.h_below : a.h;
@@ -183,52 +216,85 @@ __global__ __launch_bounds__(256) void lstm_layer_kernel(LstmArgs a) {
       const int r = (tid >> 3) + 32 * p;
       const int kc = (tid & 7) * 4;
       const long long ridx = below ? s_out[r] : s_prev[r];
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (ridx >= 0) v = *reinterpret_cast<const float4*>(src + (size_t)ridx * hp + kcol + kc);
-      t.a[r][kc + 0] = v.x;
-      t.a[r][kc + 1] = v.y;
-      t.a[r][kc + 2] = v.z;
-      t.a[r][kc + 3] = v.w;
+      amask[p] = ridx >= 0;  // applied at the LDS write (select, not multiply: row 0 may hold anything)
+      ra[p] = *reinterpret_cast<const float4*>(src + (size_t)(ridx >= 0 ? ridx : 0) * hp + kcol + kc);
     }
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
       const int kr = (tid >> 5) + 8 * p;
       const int cc = (tid & 31) * 4;
-      const float4 v = *reinterpret_cast<const float4*>(a.wt + (size_t)(k0 + kr) * ldw + coltile * BN + cc);
-      *reinterpret_cast<float4*>(&t.b[kr][cc]) = v;
+      rb[p] = *reinterpret_cast<const float4*>(a.wt + (size_t)(k0 + kr) * ldw + coltile * BN + cc);
     }
-    __syncthreads();
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int r = (tid >> 3) + 32 * p;
+      const int kc = (tid & 7) * 4;
+      t.a[r][kc + 0] = amask[p] ? ra[p].x : 0.0f;
+      t.a[r][kc + 1] = amask[p] ? ra[p].y : 0.0f;
+      t.a[r][kc + 2] = amask[p] ? ra[p].z : 0.0f;
+      t.a[r][kc + 3] = amask[p] ? ra[p].w : 0.0f;
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int kr = (tid >> 5) + 8 * p;
+      const int cc = (tid & 31) * 4;
+      *reinterpret_cast<float4*>(&t.b[kr][cc]) = rb[p];
+    }
+  };
+  gload(0);
+  lstore();
+  __syncthreads();
+  for (int k0 = 0; k0 < K; k0 += BK) {
+#if TSG_ABLATE >= 11
+    const bool more = false;
+#else
+    const bool more = k0 + BK < K;
+#endif
+    if (more) gload(k0 + BK);
     mma_tile(t, wave, lane, acc);
     __syncthreads();
+    if (more) {
+      lstore();
+      __syncthreads();
+    }
   }
-  // fused cell update: lane holds i,f,g,o of (row, unit) in acc[0..3][i]
-  const int u = coltile * 32 + (lane & 31);
-  const int gcol = coltile * BN + (lane & 31);
+  // fused cell update: lane holds i,f,g,o of (row, unit) in acc[0..3][i].  Layer 0 still owes the time
+  // term tproj[tcode] (an 11 MB, cache-resident table): fetched here four rows ahead of its use.
+  float tq[4][4];
+  auto tload = [&](int i, float dst[4]) {
+    const int r = wave * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+    const float* tp = a.tproj + (size_t)s_tc[r] * ldw + gcol;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) dst[g] = tp[g * 32];
+  };
+  if (a.layer == 0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) tload(i, tq[i]);
+  }
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     const int r = wave * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
-    if (row0 + r >= n) continue;
-    float add[4];
+    float tv[4] = {0.f, 0.f, 0.f, 0.f};
     if (a.layer == 0) {
-      const float* xp = a.xproj + (size_t)s_rid[r] * ldw + gcol;
-      const float* tp = a.tproj + (size_t)s_tc[r] * ldw + gcol;
 #pragma unroll
-      for (int g = 0; g < 4; ++g) add[g] = xp[g * 32] + tp[g * 32];
-    } else {
-#pragma unroll
-      for (int g = 0; g < 4; ++g) add[g] = a.bias[gcol + g * 32];
+      for (int g = 0; g < 4; ++g) tv[g] = tq[i & 3][g];
+      if (i + 4 < 16) tload(i + 4, tq[i & 3]);
     }
-    const float zi = acc[0][i] + add[0];
-    const float zf = acc[1][i] + add[1];
-    const float zg = acc[2][i] + add[2];
-    const float zo = acc[3][i] + add[3];
-    const long long pv = s_prev[r];
-    const float cp = pv >= 0 ? a.c[(size_t)pv * hp + u] : 0.0f;
-    const float cn = tsg_sigmoid(zf) * cp + tsg_sigmoid(zi) * tanhf(zg);
-    const float hn = tsg_sigmoid(zo) * tanhf(cn);
+    const float zi = acc[0][i] + addv[0][i] + tv[0], zf = acc[1][i] + addv[1][i] + tv[1];
+    const float zg = acc[2][i] + addv[2][i] + tv[2], zo = acc[3][i] + addv[3][i] + tv[3];
+    const float cp = s_prev[r] >= 0 ? cprev[i] : 0.0f;
+    const float cn = tsg_sigmoid(zf) * cp + tsg_sigmoid(zi) * tsg_tanh(zg);
+    const float hn = tsg_sigmoid(zo) * tsg_tanh(cn);
+    if (row0 + r >= n) continue;
     const size_t o = (size_t)s_out[r] * hp + u;
+#if TSG_ABLATE >= 13
+    if (cn == 12345.0f) a.c[o] = hn;
+#else
     a.c[o] = cn;
     a.h[o] = hn;
+#endif
   }
 }
 

@@ -269,6 +269,7 @@ __global__ __launch_bounds__(64) void frontier_kernel(EngineDev D, int superstep
   const tsg_od_batch& od = D.od;
   int32_t* counters = D.e.counters;
   int32_t* item_cnt = &counters[superstep & 1];
+  int32_t* shared = D.e.shared_counters;  // OD queue + completion, common to all sub-engines of a batch
   uint64_t* heap = D.e.heap + (size_t)b * D.e.heap_cap;
   uint32_t* table = D.e.table + (size_t)b * g.n_roads;
   int32_t* nodes = D.e.nodes + (size_t)b * D.e.node_cap * ND_WORDS;
@@ -348,7 +349,7 @@ __global__ __launch_bounds__(64) void frontier_kernel(EngineDev D, int superstep
         phase = PH_DONE;
         break;
       }
-      odi = atomicAdd(&counters[CT_NEXT_OD], 1);
+      odi = atomicAdd(&shared[CT_NEXT_OD], 1);
       if (odi >= od.n_od) {
         phase = PH_DONE;
         break;
@@ -522,19 +523,19 @@ __global__ __launch_bounds__(64) void frontier_kernel(EngineDev D, int superstep
       od.out_status[odi] = fin_status;
       od.out_steps[odi] = step;
       if (od.poplog_n) od.poplog_n[odi] = npop;
-      atomicAdd(&counters[CT_EXPANSIONS], step);
-      atomicAdd(&counters[CT_FINISHED], 1);
+      atomicAdd(&shared[CT_EXPANSIONS], step);
+      atomicAdd(&shared[CT_FINISHED], 1);
     }
     phase = PH_IDLE;
   }
   if (err) {
     // a workspace cap was hit: report, finish the OD as OVERFLOW so that the batch still terminates
-    atomicExch(&counters[CT_ERROR], 1);
+    atomicExch(&shared[CT_ERROR], 1);
     if (odi >= 0 && odi < od.n_od) {
       od.out_len[odi] = 0;
       od.out_status[odi] = TSG_STATUS_OVERFLOW;
       od.out_steps[odi] = step;
-      atomicAdd(&counters[CT_FINISHED], 1);
+      atomicAdd(&shared[CT_FINISHED], 1);
     }
     phase = PH_IDLE;
   }
@@ -579,6 +580,7 @@ static int check_engine(const tsg_model* m, const tsg_graph* g, const tsg_od_bat
   if (!e->items || e->items_bytes < B * IT_WORDS * 4) return TSG_E_TOO_SMALL;
   if (!e->cand_lp || e->cand_lp_bytes < B * (size_t)g->max_degree * 4) return TSG_E_TOO_SMALL;
   if (!e->counters || e->counters_bytes < 16 * 4) return TSG_E_TOO_SMALL;
+  if (!e->shared_counters) return TSG_E_INVALID;
   if (m) {
     if (m->hp <= 0 || (m->hp % 64) != 0 || m->hp > 512) return TSG_E_INVALID;
     if (m->n_layers < 1 || m->n_layers > TSG_MAX_LAYERS) return TSG_E_INVALID;

@@ -246,13 +246,20 @@ class GraphTables(object):
 
 
 class AStarEngine(object):
-    """Workspaces + superstep loop of the batched A* (tsg_engine_run)."""
+    """Workspaces + superstep loop of the batched A* (tsg_engine_run).
 
-    def __init__(self, tables, graph, slots, max_step, max_prefix=1, lmax=256):
+    `streams` sub-engines share one OD queue (tsg_engine.shared_counters) and run on their own HIP streams:
+    while one sub-engine is in its latency-bound frontier / scoring kernels, another keeps the matrix cores
+    busy with its LSTM step.  Workspaces are disjoint slices of the same tensors."""
+
+    def __init__(self, tables, graph, slots, max_step, max_prefix=1, lmax=256, streams=1):
         self.tables, self.graph = tables, graph
         dev = self.device = tables.device
         n = graph.num_roads
-        self.slots = B = int(slots)
+        streams = max(1, min(int(streams), int(slots)))
+        self.n_sub = streams
+        self.sub_slots = int(slots) // streams
+        self.slots = B = self.sub_slots * streams
         self.max_step, self.max_prefix, self.lmax = int(max_step), int(max_prefix), int(lmax)
         self.exp_cap = self.max_prefix + self.max_step
         self.node_cap = int(min(n, 1 + self.max_step * graph.max_degree)) + 1
@@ -272,19 +279,26 @@ class AStarEngine(object):
         self.c = [torch.empty((B * self.exp_cap, hp), dtype=f32, device=dev) for _ in range(nl)]
         self.items = torch.empty((B, 8), dtype=i32, device=dev)
         self.cand_lp = torch.empty((B, graph.max_degree), dtype=f32, device=dev)
-        self.counters = torch.zeros(16, dtype=i32, device=dev)
-        e = _lib.Engine()
-        e.slots, e.exp_cap, e.node_cap, e.heap_cap = B, self.exp_cap, self.node_cap, self.heap_cap
-        for name in ('slot_state', 'heap', 'table', 'nodes', 'exp_meta', 'exp_up', 'items', 'cand_lp', 'counters'):
-            t = getattr(self, name)
-            setattr(e, name, t.data_ptr())
-            setattr(e, name + '_bytes', t.numel() * t.element_size())
-        for l in range(nl):
-            e.h[l] = self.h[l].data_ptr()
-            e.c[l] = self.c[l].data_ptr()
-        e.state_bytes = self.h[0].numel() * 4
-        e.up_levels = self.up_levels
-        self.c_engine = e
+        self.counters = torch.zeros((streams + 1, 16), dtype=i32, device=dev)   # row `streams` = shared
+        self.c_engines = []
+        sb = self.sub_slots
+        for k in range(streams):
+            e = _lib.Engine()
+            e.slots, e.exp_cap, e.node_cap, e.heap_cap = sb, self.exp_cap, self.node_cap, self.heap_cap
+            for name in ('slot_state', 'heap', 'table', 'nodes', 'exp_meta', 'exp_up', 'items', 'cand_lp'):
+                t = getattr(self, name)[k * sb:(k + 1) * sb]
+                setattr(e, name, t.data_ptr())
+                setattr(e, name + '_bytes', t.numel() * t.element_size())
+            for l in range(nl):
+                e.h[l] = self.h[l][k * sb * self.exp_cap:].data_ptr()
+                e.c[l] = self.c[l][k * sb * self.exp_cap:].data_ptr()
+            e.state_bytes = sb * self.exp_cap * hp * 4
+            e.up_levels = self.up_levels
+            e.counters = self.counters[k].data_ptr()
+            e.counters_bytes = 64
+            e.shared_counters = self.counters[streams].data_ptr()
+            self.c_engines.append(e)
+        self.side_streams = [torch.cuda.Stream(device=dev) for _ in range(streams)] if streams > 1 else None
         self.last_stats = {}
 
     @staticmethod
@@ -353,43 +367,73 @@ class AStarEngine(object):
             pl_prio = torch.zeros((n_od, poplog_cap), dtype=torch.float32, device=dev)
             pl_n = torch.zeros(n_od, dtype=i32, device=dev)
             od.poplog_rid, od.poplog_prio, od.poplog_n = _lib.ptr(pl_rid), _lib.ptr(pl_prio), _lib.ptr(pl_n)
-        stream = _lib.current_stream()
-        m, g, e = self.tables.c_model, self.graph.c_graph, self.c_engine
+        m, g = self.tables.c_model, self.graph.c_graph
+        K = self.n_sub
+        main = torch.cuda.current_stream(dev)
+        streams = self.side_streams if K > 1 else [main]
+        handles = [C.c_void_p(s.cuda_stream) for s in streams]
         supersteps = 0
         nk = 2 + _lib.TSG_MAX_LAYERS
         prof_ms = (C.c_float * nk)()
         prof_n = (C.c_int32 * nk)()
         prof_items = 0
         chunk_i = 0
+        inflight = [[] for _ in range(K)]       # events of the chunks enqueued per stream (<= 2 kept in flight)
         with torch.cuda.device(dev):
-            _lib.check(L.tsg_engine_reset(C.byref(e), C.byref(g), stream), 'tsg_engine_reset')
+            self.counters.zero_()
+            for k in range(K):
+                if K > 1:
+                    streams[k].wait_stream(main)
+                _lib.check(L.tsg_engine_reset(C.byref(self.c_engines[k]), C.byref(g), handles[k]), 'tsg_engine_reset')
             # every superstep each unfinished slot advances by >= 1 expansion / prefix element / finished OD
             bound = (math.ceil(n_od / self.slots) + 1) * (self.max_step + self.max_prefix + 2) + 8
             while True:
                 if profile_every and chunk_i % profile_every == 0:
-                    items0 = int(self.counters[7])
-                    _lib.check(L.tsg_engine_run_profiled(C.byref(m), C.byref(g), C.byref(od), C.byref(e), supersteps,
-                                                         chunk, stream, prof_ms, prof_n), 'tsg_engine_run_profiled')
+                    # sampled chunk: drain every stream, then time each sub-engine's kernels on their own
+                    for s in streams:
+                        s.synchronize()
+                    items0 = int(self.counters[:K, 7].sum())
+                    for k in range(K):
+                        _lib.check(L.tsg_engine_run_profiled(C.byref(m), C.byref(g), C.byref(od),
+                                                             C.byref(self.c_engines[k]), supersteps, chunk, handles[k],
+                                                             prof_ms, prof_n), 'tsg_engine_run_profiled')
                     cnt = self.counters.cpu()
-                    prof_items += int(cnt[7]) - items0
+                    prof_items += int(cnt[:K, 7].sum()) - items0
                 else:
-                    _lib.check(L.tsg_engine_run(C.byref(m), C.byref(g), C.byref(od), C.byref(e), supersteps, chunk,
-                                                stream), 'tsg_engine_run')
-                    cnt = self.counters.cpu()
+                    for k in range(K):
+                        if len(inflight[k]) >= 2:
+                            inflight[k].pop(0).synchronize()
+                        _lib.check(L.tsg_engine_run(C.byref(m), C.byref(g), C.byref(od), C.byref(self.c_engines[k]),
+                                                    supersteps, chunk, handles[k]), 'tsg_engine_run')
+                        ev = torch.cuda.Event()
+                        ev.record(streams[k])
+                        inflight[k].append(ev)
+                    if K == 1:
+                        cnt = self.counters.cpu()
+                    else:
+                        inflight[0][0].synchronize()      # oldest chunk of stream 0: bounds the host run-ahead
+                        cnt = self.counters.cpu()         # racy read of monotonic counters: only ever behind
                 supersteps += chunk
                 chunk_i += 1
-                if int(cnt[3]) >= n_od:
+                if int(cnt[K, 3]) >= n_od:
                     break
                 if supersteps > bound:
                     raise RuntimeError('A* engine did not finish within %d supersteps (finished %d of %d)'
-                                       % (bound, int(cnt[3]), n_od))
-        if int(cnt[6]) != 0:
+                                       % (bound, int(cnt[K, 3]), n_od))
+            for s in streams:
+                s.synchronize()
+            if K > 1:
+                for s in streams:
+                    main.wait_stream(s)
+            cnt = self.counters.cpu()
+        if int(cnt[K, 6]) != 0:
             raise RuntimeError('A* engine hit a workspace cap (node/heap/exp capacity)')
         st = self.slot_state.to(torch.int64).sum(dim=0).cpu()
-        self.last_stats = {'supersteps': supersteps, 'expansions': int(cnt[4]), 'model_evals': int(st[27]),
-                           'n_od': n_od, 'items': int(cnt[7]),
+        self.last_stats = {'supersteps': supersteps, 'expansions': int(cnt[K, 4]), 'model_evals': int(st[27]),
+                           'n_od': n_od, 'items': int(cnt[:K, 7].sum()),
                            'chain_sum': int(st[29]), 'cand_sum': int(st[28]),
-                           'prof_ms': list(prof_ms), 'prof_launches': list(prof_n), 'prof_items': prof_items}
+                           'prof_ms': list(prof_ms), 'prof_launches': list(prof_n), 'prof_items': prof_items,
+                           'sub_engines': K}
         res = {'rid': out_rid, 'time': out_time, 'len': out_len, 'status': out_status, 'steps': out_steps}
         if poplog_cap > 0:
             res.update({'poplog_rid': pl_rid, 'poplog_prio': pl_prio, 'poplog_n': pl_n})

@@ -45,20 +45,21 @@ class Searcher(object):
                                       self.road_time_distribution)
         return self._graph
 
-    def _engine(self, gen_model, slots, max_step, max_prefix, lmax):
+    def _engine(self, gen_model, slots, max_step, max_prefix, lmax, streams=1):
         tables = gen_model.tables()
-        key = (id(tables), slots, max_step, max_prefix, lmax)
+        key = (id(tables), slots, max_step, max_prefix, lmax, streams)
         eng = self._engines.get(key)
         if eng is None:
             self._engines.clear()       # one engine's workspaces at a time
-            eng = AStarEngine(tables, self.graph(), slots, max_step, max_prefix, lmax)
+            eng = AStarEngine(tables, self.graph(), slots, max_step, max_prefix, lmax, streams)
             self._engines[key] = eng
         return eng
 
     # -- batched entry (new) ---------------------------------------------------------------------
     @torch.no_grad()
     def generate(self, gen_model, start_rids, start_times, des_rids, default_lens, max_step=500, prefixes=None,
-                 allow_label=None, slots=None, lmax=256, poplog_cap=0, return_device=False, profile_every=0):
+                 allow_label=None, slots=None, lmax=256, poplog_cap=0, return_device=False, profile_every=0,
+                 streams=None):
         """Road-level A* for many OD pairs.
 
         start_rids/start_times/des_rids/default_lens: int arrays of length n (prefix = one element), or pass
@@ -84,7 +85,9 @@ class Searcher(object):
         tables = gen_model.tables()
         if slots is None:
             slots = _auto_slots(tables, self.graph(), ms_cap, max_prefix, n_od, self.device)
-        eng = self._engine(gen_model, int(slots), ms_cap, max_prefix, lmax)
+        if streams is None:
+            streams = 1
+        eng = self._engine(gen_model, int(slots), ms_cap, max_prefix, lmax, int(streams))
         res = eng.run(prefix_ptr, prefix_rid, prefix_time, des, np.asarray(default_lens, dtype=np.int32), ms,
                       allow_label=allow_label, poplog_cap=poplog_cap, return_device=return_device,
                       profile_every=profile_every)
