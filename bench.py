@@ -142,7 +142,8 @@ def main():
                                 profile_every=profile_every, streams=args.streams)
         if world > 1:   # the single exchange step of the path: collect the padded trajectories (RCCL over xGMI)
             packed = torch.cat([res['rid'], res['time'], res['len'].unsqueeze(1), res['status'].unsqueeze(1)], dim=1)
-            gathered = torch.empty((world,) + tuple(packed.shape), dtype=packed.dtype, device=packed.device)
+            gathered = torch.empty((world * packed.shape[0], packed.shape[1]), dtype=packed.dtype,
+                                   device=packed.device)
             dist.all_gather_into_tensor(gathered, packed)
             res['gathered'] = gathered
         return res

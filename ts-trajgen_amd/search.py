@@ -88,10 +88,26 @@ class Searcher(object):
         if streams is None:
             streams = 1
         eng = self._engine(gen_model, int(slots), ms_cap, max_prefix, lmax, int(streams))
-        res = eng.run(prefix_ptr, prefix_rid, prefix_time, des, np.asarray(default_lens, dtype=np.int32), ms,
-                      allow_label=allow_label, poplog_cap=poplog_cap, return_device=return_device,
-                      profile_every=profile_every)
-        self.last_stats = eng.last_stats
+        dl = np.asarray(default_lens, dtype=np.int32)
+        al = None if allow_label is None else np.broadcast_to(np.asarray(allow_label, dtype=np.int32), (n_od,))
+        # a slot serves at most TSG_GEN_MAX searches per batch (rid-table generations): split huge batches
+        per_run = max(1, eng.slots) * 3000
+        parts, stats = [], []
+        for lo in range(0, max(n_od, 1), per_run):
+            hi = min(n_od, lo + per_run)
+            sub_ptr = prefix_ptr[lo:hi + 1] - prefix_ptr[lo]
+            p0, p1 = int(prefix_ptr[lo]), int(prefix_ptr[hi])
+            parts.append(eng.run(sub_ptr, prefix_rid[p0:p1], prefix_time[p0:p1], des[lo:hi], dl[lo:hi], ms[lo:hi],
+                                 allow_label=None if al is None else al[lo:hi], poplog_cap=poplog_cap,
+                                 return_device=return_device, profile_every=profile_every))
+            stats.append(eng.last_stats)
+        if len(parts) == 1:
+            res = parts[0]
+            self.last_stats = stats[0]
+        else:
+            res = {k: torch.cat([p[k] for p in parts], dim=0) for k in parts[0]}
+            self.last_stats = {k: (sum(s[k] for s in stats) if not isinstance(stats[0][k], list)
+                                   else [sum(x) for x in zip(*[s[k] for s in stats])]) for k in stats[0]}
         return res
 
     # -- reference API (one OD per call) ---------------------------------------------------------
