@@ -11,9 +11,16 @@ def main(paths, out):
     for path in paths:
         for fn in glob.glob(path + '/**/*counter_collection.csv', recursive=True):
             with open(fn) as f:
-                for row in csv.DictReader(f):
+                rows = sorted(csv.DictReader(f), key=lambda r: int(r['Dispatch_Id']))
+                seen = {}
+                for row in rows:
                     k = row['Kernel_Name'].split('(')[0]
                     c = row['Counter_Name']
+                    if k == 'lstm_layer_kernel':      # launches alternate layer 0, layer 1 (2-layer LSTM)
+                        d = row['Dispatch_Id']
+                        if d not in seen:
+                            seen[d] = len(seen) % 2
+                        k = 'lstm_layer_kernel[l%d]' % seen[d]
                     acc[k][c] += float(row['Counter_Value'])
                     cnt[k][c] += 1
     with open(out, 'w') as f:

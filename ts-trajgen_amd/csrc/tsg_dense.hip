@@ -127,6 +127,7 @@ struct LstmArgs {
   const float* bias;   // layer >= 1
 };
 
+template <bool LAYER0>
 __global__ __launch_bounds__(256, 2) void lstm_layer_kernel(LstmArgs a) {
   __shared__ TileLds t;
   __shared__ long long s_prev[BM];
@@ -159,7 +160,7 @@ __global__ __launch_bounds__(256, 2) void lstm_layer_kernel(LstmArgs a) {
       } else {
         pv = a.prev_idx[m];
         ov = a.out_idx[m];
-        if (a.layer == 0) {
+        if (LAYER0) {
           rd = a.rid[m];
           tc = a.tcode[m];
         }
@@ -171,77 +172,70 @@ __global__ __launch_bounds__(256, 2) void lstm_layer_kernel(LstmArgs a) {
     s_tc[tid] = tc;
   }
   __syncthreads();
-  const int K = a.layer == 0 ? hp : 2 * hp;
+  const int K = LAYER0 ? hp : 2 * hp;
   const int ldw = 4 * hp;
   const int u = coltile * 32 + (lane & 31);
   const int gcol = coltile * BN + (lane & 31);
-  // The additive gate terms (layer 0: xproj[rid] + tproj[tcode]; layer >= 1: bias) and the previous cell
-  // state are fetched now into registers: ~150 independent gathers in flight under the K loop instead of
-  // 16 dependent round trips in the epilogue.
+  // The additive gate terms and the previous cell state are fetched in batches of independent gathers
+  // (never one dependent round trip per accumulator row).
   tsg_f32x16 acc[4];
-  float addv[4][16];
   float cprev[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     const int r = wave * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
     const long long pv = s_prev[r];
     cprev[i] = a.c[(size_t)(pv >= 0 ? pv : 0) * hp + u];  // unconditional load, masked in the epilogue
-#pragma unroll
-    for (int g = 0; g < 4; ++g) acc[g][i] = 0.0f;
   }
-  if (a.layer == 0) {
+  if (LAYER0) {  // accumulators start from the road term xproj[rid]: 64 independent gathers, one wait
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int r = wave * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
       const float* xp = a.xproj + (size_t)s_rid[r] * ldw + gcol;
 #pragma unroll
-      for (int g = 0; g < 4; ++g) addv[g][i] = xp[g * 32];
+      for (int g = 0; g < 4; ++g) acc[g][i] = xp[g * 32];
     }
   } else {
 #pragma unroll
-    for (int i = 0; i < 16; ++i)
+    for (int g = 0; g < 4; ++g) {
+      const float bv = a.bias[gcol + g * 32];
 #pragma unroll
-      for (int g = 0; g < 4; ++g) addv[g][i] = a.bias[gcol + g * 32];
+      for (int i = 0; i < 16; ++i) acc[g][i] = bv;
+    }
   }
   // software pipeline: the global loads of k-tile t+1 are issued before the MFMAs of tile t and land in
   // registers while the matrix cores work; they are written to LDS after the tile's last read.
-  float4 ra[4], rb[4];
-  bool amask[4];
+  // (named registers, not arrays: the arrays were left on the stack by the compiler)
+  float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+  unsigned am0, am1, am2, am3;
+  const int a_r = tid >> 3, a_kc = (tid & 7) * 4;   // A tile: row a_r + 32p, k chunk a_kc
+  const int b_kr = tid >> 5, b_cc = (tid & 31) * 4;  // B tile: k row b_kr + 8p, column chunk b_cc
+#define TSG_GLOAD_A(P, RA, AM)                                                                       \
+  {                                                                                                  \
+    const long long ridx = below ? s_out[a_r + 32 * P] : s_prev[a_r + 32 * P];                       \
+    AM = ridx >= 0 ? 0xffffffffu : 0u; /* ANDed in at the LDS write: row 0 may hold anything */      \
+    RA = *reinterpret_cast<const float4*>(src + (size_t)(ridx >= 0 ? ridx : 0) * hp + kcol + a_kc);  \
+  }
+#define TSG_GLOAD_B(P, RB) \
+  RB = *reinterpret_cast<const float4*>(a.wt + (size_t)(k0 + b_kr + 8 * P) * ldw + coltile * BN + b_cc);
+#define TSG_LSTORE_A(P, RA, AM)                                              \
+  {                                                                          \
+    float* dst = &t.a[a_r + 32 * P][a_kc];                                   \
+    dst[0] = __uint_as_float(__float_as_uint(RA.x) & AM);                    \
+    dst[1] = __uint_as_float(__float_as_uint(RA.y) & AM);                    \
+    dst[2] = __uint_as_float(__float_as_uint(RA.z) & AM);                    \
+    dst[3] = __uint_as_float(__float_as_uint(RA.w) & AM);                    \
+  }
+#define TSG_LSTORE_B(P, RB) *reinterpret_cast<float4*>(&t.b[b_kr + 8 * P][b_cc]) = RB;
   auto gload = [&](int k0) {
-    const bool below = (a.layer > 0) && (k0 < hp);
-    const int kcol = below ? k0 : (a.layer > 0 ? k0 - hp : k0);
+    const bool below = !LAYER0 && (k0 < hp);
+    const int kcol = below ? k0 : (!LAYER0 ? k0 - hp : k0);
     const float* src = below ? a.h_below : a.h;
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      const int r = (tid >> 3) + 32 * p;
-      const int kc = (tid & 7) * 4;
-      const long long ridx = below ? s_out[r] : s_prev[r];
-      amask[p] = ridx >= 0;  // applied at the LDS write (select, not multiply: row 0 may hold anything)
-      ra[p] = *reinterpret_cast<const float4*>(src + (size_t)(ridx >= 0 ? ridx : 0) * hp + kcol + kc);
-    }
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      const int kr = (tid >> 5) + 8 * p;
-      const int cc = (tid & 31) * 4;
-      rb[p] = *reinterpret_cast<const float4*>(a.wt + (size_t)(k0 + kr) * ldw + coltile * BN + cc);
-    }
+    TSG_GLOAD_A(0, ra0, am0) TSG_GLOAD_A(1, ra1, am1) TSG_GLOAD_A(2, ra2, am2) TSG_GLOAD_A(3, ra3, am3)
+    TSG_GLOAD_B(0, rb0) TSG_GLOAD_B(1, rb1) TSG_GLOAD_B(2, rb2) TSG_GLOAD_B(3, rb3)
   };
   auto lstore = [&]() {
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      const int r = (tid >> 3) + 32 * p;
-      const int kc = (tid & 7) * 4;
-      t.a[r][kc + 0] = amask[p] ? ra[p].x : 0.0f;
-      t.a[r][kc + 1] = amask[p] ? ra[p].y : 0.0f;
-      t.a[r][kc + 2] = amask[p] ? ra[p].z : 0.0f;
-      t.a[r][kc + 3] = amask[p] ? ra[p].w : 0.0f;
-    }
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      const int kr = (tid >> 5) + 8 * p;
-      const int cc = (tid & 31) * 4;
-      *reinterpret_cast<float4*>(&t.b[kr][cc]) = rb[p];
-    }
+    TSG_LSTORE_A(0, ra0, am0) TSG_LSTORE_A(1, ra1, am1) TSG_LSTORE_A(2, ra2, am2) TSG_LSTORE_A(3, ra3, am3)
+    TSG_LSTORE_B(0, rb0) TSG_LSTORE_B(1, rb1) TSG_LSTORE_B(2, rb2) TSG_LSTORE_B(3, rb3)
   };
   gload(0);
   lstore();
@@ -262,28 +256,26 @@ __global__ __launch_bounds__(256, 2) void lstm_layer_kernel(LstmArgs a) {
   }
   // fused cell update: lane holds i,f,g,o of (row, unit) in acc[0..3][i].  Layer 0 still owes the time
   // term tproj[tcode] (an 11 MB, cache-resident table): fetched here four rows ahead of its use.
-  float tq[4][4];
-  auto tload = [&](int i, float dst[4]) {
+  float4 tq[4];
+  auto tload = [&](int i) {
     const int r = wave * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
     const float* tp = a.tproj + (size_t)s_tc[r] * ldw + gcol;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) dst[g] = tp[g * 32];
+    return make_float4(tp[0], tp[32], tp[64], tp[96]);
   };
-  if (a.layer == 0) {
+  if (LAYER0) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) tload(i, tq[i]);
+    for (int i = 0; i < 4; ++i) tq[i] = tload(i);
   }
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     const int r = wave * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
-    float tv[4] = {0.f, 0.f, 0.f, 0.f};
-    if (a.layer == 0) {
-#pragma unroll
-      for (int g = 0; g < 4; ++g) tv[g] = tq[i & 3][g];
-      if (i + 4 < 16) tload(i + 4, tq[i & 3]);
+    float4 tv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (LAYER0) {
+      tv = tq[i & 3];
+      if (i + 4 < 16) tq[i & 3] = tload(i + 4);
     }
-    const float zi = acc[0][i] + addv[0][i] + tv[0], zf = acc[1][i] + addv[1][i] + tv[1];
-    const float zg = acc[2][i] + addv[2][i] + tv[2], zo = acc[3][i] + addv[3][i] + tv[3];
+    const float zi = acc[0][i] + tv.x, zf = acc[1][i] + tv.y;
+    const float zg = acc[2][i] + tv.z, zo = acc[3][i] + tv.w;
     const float cp = s_prev[r] >= 0 ? cprev[i] : 0.0f;
     const float cn = tsg_sigmoid(zf) * cp + tsg_sigmoid(zi) * tsg_tanh(zg);
     const float hn = tsg_sigmoid(zo) * tsg_tanh(cn);
@@ -333,7 +325,10 @@ int tsg_launch_lstm_layer(const tsg_model* m, int layer, int max_rows, const int
   if (max_rows <= 0) return 0;
   const int rowtiles = tsg_cdiv(max_rows, BM);
   const int grid = 8 * tsg_cdiv(rowtiles, 8) * (m->hp / 32);
-  hipLaunchKernelGGL(lstm_layer_kernel, dim3(grid), dim3(256), 0, stream, a);
+  if (layer == 0)
+    hipLaunchKernelGGL(lstm_layer_kernel<true>, dim3(grid), dim3(256), 0, stream, a);
+  else
+    hipLaunchKernelGGL(lstm_layer_kernel<false>, dim3(grid), dim3(256), 0, stream, a);
   TSG_LAUNCH_CHECK();
   return 0;
 }
