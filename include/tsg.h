@@ -37,6 +37,7 @@ extern "C" {
 
 #define TSG_MAX_LAYERS 4
 #define TSG_MAX_DEGREE 64 /* successors per road the scoring kernel handles in one wave */
+#define TSG_UP_LEVELS 8   /* binary-lifting levels stored per expanded node (levels 0..6 are used) */
 #define TSG_H_HIDDEN 10   /* emb_fc / dis_fc width, hard-coded at distance_gat_fc.py:38-40 */
 
 /* per-OD result status (mirrors the three exits of search.py:421-424) */
@@ -217,7 +218,7 @@ typedef struct tsg_engine {
   int32_t* nodes;       size_t nodes_bytes;       /* [B][node_cap][8] int32 */
   int32_t* exp_meta;    size_t exp_meta_bytes;    /* [B][exp_cap][4] {parent, rid, tcode, depth} */
   int32_t* exp_up;      size_t exp_up_bytes;      /* [B][exp_cap][up_levels]: 2^k-th ancestor slot (binary lifting) */
-  int32_t up_levels;    int32_t reserved0;        /* 7 <= up_levels <= 24, 2^up_levels >= exp_cap */
+  int32_t up_levels;    int32_t reserved0;        /* must be TSG_UP_LEVELS */
   float* h[TSG_MAX_LAYERS];                       /* [B*exp_cap][Hp] per layer */
   float* c[TSG_MAX_LAYERS];
   size_t state_bytes;                             /* bytes of EACH h[l] / c[l] */

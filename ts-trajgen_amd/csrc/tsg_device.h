@@ -79,13 +79,11 @@ __device__ __forceinline__ void attn_init(AttnAcc<JT>& s) {
   for (int j = 0; j < JT; ++j) s.v[j] = 0.0f;
 }
 
-// Fold up to 4 key rows at once: 4 independent dot products and butterfly reductions in flight.
-// rows[u] == nullptr marks an absent row.
+// Attention over key rows in groups of 4: attn_load4 issues the (independent, coalesced) row loads of a
+// group, attn_fold4 folds a loaded group into the running online softmax.  The caller loads group g+1
+// before folding group g, so eight rows per wave are in flight.  rows[u] == nullptr marks an absent row.
 template <int JT>
-__device__ __forceinline__ void attn_fold4(AttnAcc<JT>& s, const float* const rows[4], const float q[JT], int J,
-                                           int lane) {
-  float key[4][JT];
-  float part[4];
+__device__ __forceinline__ void attn_load4(float key[4][JT], const float* const rows[4], int J, int lane) {
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
     if (rows[u]) {
@@ -95,6 +93,12 @@ __device__ __forceinline__ void attn_fold4(AttnAcc<JT>& s, const float* const ro
       for (int j = 0; j < JT; ++j) key[u][j] = 0.0f;
     }
   }
+}
+
+template <int JT>
+__device__ __forceinline__ void attn_fold4(AttnAcc<JT>& s, const float key[4][JT], unsigned present,
+                                           const float q[JT]) {
+  float part[4];
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
     part[u] = 0.0f;
@@ -109,13 +113,13 @@ __device__ __forceinline__ void attn_fold4(AttnAcc<JT>& s, const float* const ro
   float mn = s.m;
 #pragma unroll
   for (int u = 0; u < 4; ++u)
-    if (rows[u]) mn = fmaxf(mn, part[u]);
-  const float scale = expf(s.m - mn);  // exp(-inf) = 0 on the first fold
+    if (present & (1u << u)) mn = fmaxf(mn, part[u]);
+  const float scale = __expf(s.m - mn);  // exp(-inf) = 0 on the first fold
   float w[4];
   float wsum = 0.0f;
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
-    w[u] = rows[u] ? expf(part[u] - mn) : 0.0f;
+    w[u] = (present & (1u << u)) ? __expf(part[u] - mn) : 0.0f;
     wsum += w[u];
   }
   s.l = s.l * scale + wsum;

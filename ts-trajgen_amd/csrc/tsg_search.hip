@@ -31,9 +31,15 @@ __global__ __launch_bounds__(256) void score_batch_kernel(tsg_model m, tsg_score
   attn_init(acc);
   for (int i = c1 - 1; i >= c0; i -= 4) {
     const float* rows[4];
+    unsigned present = 0;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) rows[u] = (i - u >= c0) ? sb.h_top + (size_t)sb.chain[i - u] * hp : nullptr;
-    attn_fold4<JT>(acc, rows, q, J, lane);
+    for (int u = 0; u < 4; ++u) {
+      rows[u] = (i - u >= c0) ? sb.h_top + (size_t)sb.chain[i - u] * hp : nullptr;
+      if (rows[u]) present |= 1u << u;
+    }
+    float key[4][JT];
+    attn_load4<JT>(key, rows, J, lane);
+    attn_fold4<JT>(acc, key, present, q);
   }
   float pooled[JT];
   const float inv = 1.0f / acc.l;
@@ -84,6 +90,24 @@ struct EngineDev {
   tsg_od_batch od;
 };
 
+// Candidate distances of the superstep: one LANE per (work item, successor) pair instead of one wave per
+// item, so the fp64 Vincenty iteration runs on full wavefronts.  Writes kilometres * 10 as f32
+// (search.py:355-356) into cand_lp[slot][c], where the scoring kernel picks it up and overwrites it with
+// the candidate's log-probability.
+__global__ __launch_bounds__(256) void cand_dis_kernel(EngineDev D, int superstep) {
+  const int n_items = D.e.counters[superstep & 1];
+  const int md = D.g.max_degree;
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int idx = (int)(t / md), c = (int)(t % md);
+  if (idx >= n_items) return;
+  const int32_t* it = D.e.items + (size_t)idx * IT_WORDS;
+  const int ncand = it[IT_NCAND];
+  if (ncand < 2 || c >= ncand) return;
+  const int cand = D.g.indices[D.g.indptr[it[IT_RID]] + c];
+  const double dm = tsg_dev_geodesic_m(D.g.geo + 4 * (size_t)it[IT_DES], D.g.geo + 4 * (size_t)cand);
+  D.e.cand_lp[(size_t)it[IT_SLOT] * md + c] = (float)(dm / 1000.0 * 10.0);
+}
+
 // Ancestors are found through a binary-lifting table: up[e][k] = the 2^k-th ancestor of expanded
 // slot e (or -1).  A wave first writes the row of its own slot (one dependent load per level), then
 // lane t resolves the t-th ancestor in <= 6 dependent loads, so the key rows of the attention are
@@ -102,7 +126,7 @@ __global__ __launch_bounds__(256) void score_frontier_kernel(tsg_model m, Engine
   const int32_t* it = D.e.items + (size_t)idx * IT_WORDS;
   const int ncand = it[IT_NCAND];
   const int b = it[IT_SLOT], e = it[IT_EXP];
-  const int LV = D.e.up_levels;
+  constexpr int LV = TSG_UP_LEVELS;  // levels 0..5 resolve a lane's ancestor inside a 64-chunk, level 6 hops chunks
   int32_t* up = D.e.exp_up + (size_t)b * D.e.exp_cap * LV;
   // up[e][*]: every lane computes the same chain (wave-uniform addresses), lane 0 stores.  The first 7
   // levels stay in registers: this wave must not read back what it has just stored.
@@ -112,10 +136,6 @@ __global__ __launch_bounds__(256) void score_frontier_kernel(tsg_model m, Engine
 #pragma unroll
     for (int k = 0; k < 7; ++k) {
       mine[k] = a;
-      if (lane == 0) up[(size_t)e * LV + k] = a;
-      a = (a >= 0) ? up[(size_t)a * LV + k] : -1;
-    }
-    for (int k = 7; k < LV; ++k) {
       if (lane == 0) up[(size_t)e * LV + k] = a;
       a = (a >= 0) ? up[(size_t)a * LV + k] : -1;
     }
@@ -141,18 +161,34 @@ __global__ __launch_bounds__(256) void score_frontier_kernel(tsg_model m, Engine
       const bool hop = ((lane >> k) & 1) && cur >= 0;
       if (hop) cur = (cur == e) ? mine[k] : up[(size_t)cur * LV + k];
     }
-    for (int i = 0; i < n; i += 4) {
+    // groups of 4 rows, software-pipelined: group g+1 is loading while group g is folded
+    float keyA[4][JT], keyB[4][JT];
+    unsigned presA = 0, presB = 0;
+    auto issue = [&](int i, float key[4][JT], unsigned& pres) {
       const float* rows[4];
+      pres = 0;
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int src_lane = i + u < n ? i + u : n - 1;
         const int id = __shfl(cur, src_lane, TSG_WAVE);
         rows[u] = (i + u < n) ? htop + (size_t)id * hp : nullptr;
+        if (rows[u]) pres |= 1u << u;
       }
+      attn_load4<JT>(key, rows, J, lane);
+    };
+    issue(0, keyA, presA);
+    for (int i = 0; i < n; i += 8) {
+      if (i + 4 < n) issue(i + 4, keyB, presB);
 #if TSG_ABLATE == 2
-      if (i > 0) continue;
+      if (i == 0)
 #endif
-      attn_fold4<JT>(acc, rows, q, J, lane);
+      attn_fold4<JT>(acc, keyA, presA, q);
+      if (i + 4 < n) {
+        if (i + 8 < n) issue(i + 8, keyA, presA);
+#if TSG_ABLATE != 2
+        attn_fold4<JT>(acc, keyB, presB, q);
+#endif
+      }
     }
     if (base + 64 < depth) anchor = (anchor == e) ? mine[6] : up[(size_t)anchor * LV + 6];
   }
@@ -164,12 +200,7 @@ __global__ __launch_bounds__(256) void score_frontier_kernel(tsg_model m, Engine
   float my_dis = 0.0f;
   if (lane < ncand) {
     my_cand = D.g.indices[D.g.indptr[rid] + lane];
-#if TSG_ABLATE == 1
-    const double dm = 1234.0 + my_cand;
-#else
-    const double dm = tsg_dev_geodesic_m(D.g.geo + 4 * (size_t)des, D.g.geo + 4 * (size_t)my_cand);
-#endif
-    my_dis = (float)(dm / 1000.0 * 10.0);  // search.py:355-356
+    my_dis = D.e.cand_lp[(size_t)b * D.g.max_degree + lane];  // written by cand_dis_kernel
   }
 #if TSG_ABLATE == 3
   const float f = 1.0f / ncand + pooled[0] * 1e-9f + my_dis * 1e-9f;
@@ -177,6 +208,11 @@ __global__ __launch_bounds__(256) void score_frontier_kernel(tsg_model m, Engine
   const float f = score_row<JT>(m, pooled, J, lane, ncand, my_cand, my_dis, des, nullptr, nullptr);
 #endif
   if (lane < ncand) D.e.cand_lp[(size_t)b * D.g.max_degree + lane] = logf(f) + lp_parent;  // search.py:370-373
+}
+
+static void launch_cand_dis(const EngineDev& D, int superstep, hipStream_t s) {
+  const long threads = (long)D.e.slots * D.g.max_degree;
+  hipLaunchKernelGGL(cand_dis_kernel, dim3(tsg_cdiv(threads, 256)), dim3(256), 0, s, D, superstep);
 }
 
 static void launch_score_frontier(const tsg_model* m, const EngineDev& D, int superstep, hipStream_t s) {
@@ -586,8 +622,7 @@ static int check_engine(const tsg_model* m, const tsg_graph* g, const tsg_od_bat
     if (m->n_layers < 1 || m->n_layers > TSG_MAX_LAYERS) return TSG_E_INVALID;
     if (m->n_roads < g->n_roads) return TSG_E_INVALID;
     if (!g->geo) return TSG_E_INVALID;
-    if (e->up_levels < 7 || e->up_levels > 24) return TSG_E_INVALID;
-    if ((1L << e->up_levels) < e->exp_cap) return TSG_E_INVALID;
+    if (e->up_levels != TSG_UP_LEVELS) return TSG_E_INVALID;
     if (!e->exp_up || e->exp_up_bytes < B * e->exp_cap * (size_t)e->up_levels * 4) return TSG_E_TOO_SMALL;
     for (int l = 0; l < m->n_layers; ++l)
       if (!e->h[l] || !e->c[l] || e->state_bytes < B * e->exp_cap * (size_t)m->hp * 4) return TSG_E_TOO_SMALL;
@@ -635,6 +670,8 @@ extern "C" int tsg_score_frontier(const tsg_model* m, const tsg_graph* g, const 
   D.e = *e;
   D.g = *g;
   D.od = tsg_od_batch{};
+  launch_cand_dis(D, superstep, (hipStream_t)stream);
+  TSG_LAUNCH_CHECK();
   launch_score_frontier(m, D, superstep, (hipStream_t)stream);
   TSG_LAUNCH_CHECK();
   return 0;
@@ -654,6 +691,8 @@ extern "C" int tsg_engine_run(const tsg_model* m, const tsg_graph* g, const tsg_
   for (int k = 0; k < n_supersteps; ++k) {
     const int ss = first_superstep + k;
     hipLaunchKernelGGL(frontier_kernel, fgrid, dim3(64), 0, s, D, ss);
+    TSG_LAUNCH_CHECK();
+    launch_cand_dis(D, ss, s);
     TSG_LAUNCH_CHECK();
     const int32_t* n_items = e->counters + (ss & 1);
     for (int l = 0; l < m->n_layers; ++l) {
@@ -698,6 +737,7 @@ extern "C" int tsg_engine_run_profiled(const tsg_model* m, const tsg_graph* g, c
     const int ss = first_superstep + k;
     (void)hipEventRecord(ev[q++], s);
     hipLaunchKernelGGL(frontier_kernel, fgrid, dim3(64), 0, s, D, ss);
+    launch_cand_dis(D, ss, s);  // timed with the frontier kernel
     (void)hipEventRecord(ev[q++], s);
     const int32_t* n_items = e->counters + (ss & 1);
     for (int l = 0; l < m->n_layers && rc == 0; ++l) {

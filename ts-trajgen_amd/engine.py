@@ -273,7 +273,7 @@ class AStarEngine(object):
         self.table = torch.zeros((B, n), dtype=i32, device=dev)
         self.nodes = torch.empty((B, self.node_cap, 8), dtype=i32, device=dev)
         self.exp_meta = torch.empty((B, self.exp_cap, 4), dtype=i32, device=dev)
-        self.up_levels = max(7, int(math.ceil(math.log2(max(2, self.exp_cap)))))
+        self.up_levels = 8      # TSG_UP_LEVELS
         self.exp_up = torch.empty((B, self.exp_cap, self.up_levels), dtype=i32, device=dev)
         self.h = [torch.empty((B * self.exp_cap, hp), dtype=f32, device=dev) for _ in range(nl)]
         self.c = [torch.empty((B * self.exp_cap, hp), dtype=f32, device=dev) for _ in range(nl)]
@@ -307,7 +307,7 @@ class AStarEngine(object):
         node_cap = min(graph.num_roads, 1 + max_step * graph.max_degree) + 1
         heap_cap = 1 + max_step * graph.max_degree
         return (2 * tables.n_layers * exp_cap * tables.hp * 4 + heap_cap * 8 + graph.num_roads * 4
-                + node_cap * 32 + exp_cap * (16 + 4 * 14) + 32 * 4 + 32 + graph.max_degree * 4)
+                + node_cap * 32 + exp_cap * (16 + 4 * 8) + 32 * 4 + 32 + graph.max_degree * 4)
 
     @torch.no_grad()
     def run(self, prefix_ptr, prefix_rid, prefix_time, des, default_len, max_step, allow_label=None,
