@@ -183,6 +183,10 @@ typedef struct tsg_graph {
                              with the reduced-latitude terms of the WGS-84 inverse geodesic precomputed (fp64) */
   const int32_t* cost;    /* [24][n_roads] seconds: rtd if != 1 else int(round(len/8.334)) (search.py:376-381) */
   const int32_t* label;   /* [n_roads] region label per road, or NULL (no in-region gating) */
+  /* region-level graphs (DoubleLayerSearcher.astar_search_in_region, search.py:936-1117); NULL for roads: */
+  const double* dist_table;   /* [n][n] metres: candidate distance = dist_table[c][des] / 100 (search.py:1049) */
+  const int32_t* pair_cost;   /* [n][n] seconds int(round(dist[now][c] / 8.334)), used where cost[h][now] < 0 */
+  const uint8_t* empty_key;   /* [n] 1 = node has a key with no successors: closed without a step (:993-995) */
 } tsg_graph;
 
 typedef struct tsg_od_batch {

@@ -161,3 +161,35 @@ def test_g6_astar_in_region(road, road_model, region):
         loc, tim = s.astar_search_in_region(road_model, c['prefix_loc'], c['prefix_tim'], c['des'],
                                             c['default_len'], rset, max_step=c['max_step'])
         assert loc == c['loc'] and tim == c['tim']
+
+
+def test_g7_double_layer(road, road_model, region):
+    """Two-stage search (search.py:859-934): region A*, border-road legs, last leg; per-OD RandomState."""
+    from ts_trajgen_amd.search import DoubleLayerSearcher
+    region_model = build_generator(region, DEV)
+    t = region.tables(road)
+    s = DoubleLayerSearcher(DEV, t['adjacent_list'], t['road_center_gps'], t['road_length'],
+                            t['region_adjacent_list'], t['region_dist'], t['region_transfer_freq'],
+                            t['rid2region'], t['region2rid'], road.rtd, region.npz['region_time_distribution'])
+    cases = region.meta['cases']
+    # region stage alone (search.py:936-1117)
+    for c in cases[:6]:
+        tr, fl = s.astar_search_in_region(region_model, t['rid2region'][str(c['start'])], c['start_time'],
+                                          t['rid2region'][str(c['des'])], c['max_step'])
+        assert tr == c['region_trace'] and fl == c['region_flag']
+    loc, tim, fl = s.generate(region_model, road_model, [c['start'] for c in cases],
+                              [c['start_time'] for c in cases], [c['des'] for c in cases],
+                              [c['default_len'] for c in cases], max_step=[c['max_step'] for c in cases],
+                              seeds=[c['seed'] for c in cases])
+    same = sum(int(loc[i] == c['loc'] and tim[i] == c['tim'] and fl[i] == c['is_astar'])
+               for i, c in enumerate(cases))
+    assert same >= len(cases) - 1, same
+    if same == len(cases):
+        assert sorted([list(map(int, x)) for x in s.fail_find_log]) == region.meta['fail_find_log']
+        assert sorted([list(map(int, x)) for x in s.region_fail_find_log]) == region.meta['region_fail_find_log']
+    # reference one-OD signature with the global numpy RNG (search.py:859)
+    c = cases[3]
+    np.random.seed(c['seed'])
+    l1, t1, f1 = s.astar_search(region_model, road_model, c['start'], c['start_time'], c['des'], c['default_len'],
+                                max_step=c['max_step'])
+    assert l1 == c['loc'] and t1 == c['tim'] and f1 == c['is_astar']

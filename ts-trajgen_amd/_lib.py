@@ -50,7 +50,7 @@ class ScoreBatch(C.Structure):
 
 class Graph(C.Structure):
     _fields_ = [('n_roads', _i32), ('max_degree', _i32), ('indptr', _p), ('indices', _p), ('geo', _p),
-                ('cost', _p), ('label', _p)]
+                ('cost', _p), ('label', _p), ('dist_table', _p), ('pair_cost', _p), ('empty_key', _p)]
 
 
 class OdBatch(C.Structure):

@@ -104,8 +104,14 @@ __global__ __launch_bounds__(256) void cand_dis_kernel(EngineDev D, int superste
   const int ncand = it[IT_NCAND];
   if (ncand < 2 || c >= ncand) return;
   const int cand = D.g.indices[D.g.indptr[it[IT_RID]] + c];
-  const double dm = tsg_dev_geodesic_m(D.g.geo + 4 * (size_t)it[IT_DES], D.g.geo + 4 * (size_t)cand);
-  D.e.cand_lp[(size_t)it[IT_SLOT] * md + c] = (float)(dm / 1000.0 * 10.0);
+  float dis;
+  if (D.g.dist_table) {  // region graphs: region_dist[c][des] / 100 (search.py:1049)
+    dis = (float)(D.g.dist_table[(size_t)cand * D.g.n_roads + it[IT_DES]] / 100.0);
+  } else {
+    const double dm = tsg_dev_geodesic_m(D.g.geo + 4 * (size_t)it[IT_DES], D.g.geo + 4 * (size_t)cand);
+    dis = (float)(dm / 1000.0 * 10.0);
+  }
+  D.e.cand_lp[(size_t)it[IT_SLOT] * md + c] = dis;
 }
 
 // Ancestors are found through a binary-lifting table: up[e][k] = the 2^k-th ancestor of expanded
@@ -321,14 +327,19 @@ __global__ __launch_bounds__(64) void frontier_kernel(EngineDev D, int superstep
 
   // ---- relax the expansion scored during the previous superstep (search.py:385-419 / 317-350)
   if (phase == PH_EXPANDED) {
-    const int e = S[SS_CUR_EXP], C = S[SS_CUR_C], rid = S[SS_CUR_RID], next_time = S[SS_CUR_NEXT_TIME];
+    const int e = S[SS_CUR_EXP], C = S[SS_CUR_C], rid = S[SS_CUR_RID];
+    const int cur_date_time = S[SS_CUR_DATE_TIME], cur_cost = S[SS_CUR_COST];
     const float lp_parent = __int_as_float(S[SS_CUR_LP]);
     const int child_depth = S[SS_CUR_DEPTH] + 1;
-    const int tcode_child = next_time / 60 + woff;
     const int base = g.indptr[rid];
     for (int i = 0; i < C; ++i) {
       const int c = g.indices[base + i];
       const float lp = (C == 1) ? lp_parent : D.e.cand_lp[(size_t)b * g.max_degree + i];
+      // travel time of the expanded road (search.py:376-382); region graphs fall back to a per-pair
+      // cost when the region's time distribution is unknown (search.py:1073-1078)
+      const int cost = cur_cost >= 0 ? cur_cost : g.pair_cost[(size_t)rid * g.n_roads + c];
+      const int next_time = (cur_date_time + cost) % 86400;
+      const int tcode_child = next_time / 60 + woff;
       const uint32_t t = table[c];
       bool pushed = false;
       int idx = -1;
@@ -475,6 +486,10 @@ __global__ __launch_bounds__(64) void frontier_kernel(EngineDev D, int superstep
       const int beg = g.indptr[rid];
       const int C = g.indptr[rid + 1] - beg;
       const bool gate = C > 0 && (allow < 0 || (g.label && g.label[rid] == allow));  // search.py:300 / :487
+      if (C == 0 && g.empty_key && g.empty_key[rid]) {  // key present, no successors: `continue` (search.py:993-995)
+        nd[ND_EXP] = ND_CLOSED_NOSLOT;
+        continue;
+      }
       ++step;  // search.py:420
       if (!gate) {
         nd[ND_EXP] = ND_CLOSED_NOSLOT;
@@ -491,12 +506,12 @@ __global__ __launch_bounds__(64) void frontier_kernel(EngineDev D, int superstep
       em[(size_t)e * EM_WORDS + EM_TCODE] = tcode;
       em[(size_t)e * EM_WORDS + EM_DEPTH] = depth;
       const int hour = date_time / 3600;                                   // search.py:376
-      const int cost = g.cost[(size_t)hour * g.n_roads + rid];              // search.py:377-381 (pre-resolved)
-      const int next_time = (date_time + cost) % 86400;                     // search.py:382
+      const int cost = g.cost[(size_t)hour * g.n_roads + rid];              // search.py:377-381 (pre-resolved; <0: per pair)
       S[SS_CUR_EXP] = e;
       S[SS_CUR_RID] = rid;
       S[SS_CUR_C] = C;
-      S[SS_CUR_NEXT_TIME] = next_time;
+      S[SS_CUR_DATE_TIME] = date_time;
+      S[SS_CUR_COST] = cost;
       S[SS_CUR_LP] = nd[ND_LP];
       S[SS_CUR_DEPTH] = depth;
       if (C > 1) {  // per-slot statistics (summed on the host; no same-address atomics on the hot path)
@@ -605,6 +620,7 @@ static int check_engine(const tsg_model* m, const tsg_graph* g, const tsg_od_bat
   if (!g || !e) return TSG_E_INVALID;
   if (g->n_roads <= 0 || g->max_degree <= 0 || !g->indptr || !g->indices || !g->cost) return TSG_E_INVALID;
   if (g->max_degree > TSG_MAX_DEGREE) return TSG_E_LIMIT;
+  if (g->dist_table && !g->pair_cost) return TSG_E_INVALID;
   if (e->slots <= 0 || e->exp_cap <= 0 || e->node_cap <= 0 || e->heap_cap <= 0) return TSG_E_INVALID;
   if ((unsigned)e->node_cap > TSG_NODE_MASK) return TSG_E_LIMIT;
   const size_t B = (size_t)e->slots;
@@ -621,7 +637,7 @@ static int check_engine(const tsg_model* m, const tsg_graph* g, const tsg_od_bat
     if (m->hp <= 0 || (m->hp % 64) != 0 || m->hp > 512) return TSG_E_INVALID;
     if (m->n_layers < 1 || m->n_layers > TSG_MAX_LAYERS) return TSG_E_INVALID;
     if (m->n_roads < g->n_roads) return TSG_E_INVALID;
-    if (!g->geo) return TSG_E_INVALID;
+    if (!g->geo && !g->dist_table) return TSG_E_INVALID;
     if (e->up_levels != TSG_UP_LEVELS) return TSG_E_INVALID;
     if (!e->exp_up || e->exp_up_bytes < B * e->exp_cap * (size_t)e->up_levels * 4) return TSG_E_TOO_SMALL;
     for (int l = 0; l < m->n_layers; ++l)

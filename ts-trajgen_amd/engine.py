@@ -230,6 +230,51 @@ class GraphTables(object):
             self.set_labels(rid_label)
         self._build()
 
+    @classmethod
+    def for_regions(cls, device, region_adjacent_list, region_dist, region_time_distribution, num_regions=None):
+        """Region-level graph of DoubleLayerSearcher.astar_search_in_region (search.py:936-1117):
+        successors = keys of region_adjacent_list[str(r)] in dict order (:992), candidate distance =
+        region_dist[c][des] / 100 (:1049), per-candidate travel time where the region's time distribution
+        is unknown (:1073-1078), regions whose key holds no successor are closed without a step (:993-995)."""
+        self = cls.__new__(cls)
+        self.device = torch.device(device)
+        region_dist = np.asarray(region_dist, dtype=np.float64)
+        n = self.num_roads = int(num_regions if num_regions is not None else region_dist.shape[0])
+        if region_dist.shape[0] < n or region_dist.shape[1] < n:
+            raise ValueError('region_dist smaller than the number of regions')
+        indptr = np.zeros(n + 1, dtype=np.int32)
+        lists = []
+        empty = np.zeros(n, dtype=np.uint8)
+        for r in range(n):
+            d = region_adjacent_list.get(str(r))
+            keys = [int(k) for k in d.keys()] if d is not None else []
+            if d is not None and len(keys) == 0:
+                empty[r] = 1
+            lists.append(keys)
+            indptr[r + 1] = indptr[r] + len(keys)
+        indices = np.array([c for l in lists for c in l], dtype=np.int32)
+        if len(indices) and (indices.min() < 0 or indices.max() >= n):
+            raise ValueError('region_adjacent_list refers to a region outside [0, %d)' % n)
+        self.max_degree = int(max(1, np.diff(indptr).max() if n else 1))
+        if self.max_degree > _lib.TSG_MAX_DEGREE:
+            raise ValueError('region out-degree %d exceeds the kernel limit %d' % (self.max_degree, _lib.TSG_MAX_DEGREE))
+        rtd = np.asarray(region_time_distribution).astype(int)[:, :n]
+        cost = np.where(rtd != 1, rtd, -1).astype(np.int32)          # -1: use the per-pair cost
+        dist = np.ascontiguousarray(region_dist[:n, :n])
+        pair = np.rint(dist / DEFAULT_SPEED).astype(np.int32)        # int(round(.)): half-to-even like Python
+        dev = self.device
+        self.indptr_np, self.indices_np = indptr, indices
+        self.indptr = torch.from_numpy(indptr).to(dev)
+        self.indices = torch.from_numpy(indices if len(indices) else np.zeros(1, np.int32)).to(dev)
+        self.geo = None
+        self.cost = torch.from_numpy(np.ascontiguousarray(cost)).to(dev)
+        self.label = None
+        self.dist_table = torch.from_numpy(dist).to(dev)
+        self.pair_cost = torch.from_numpy(np.ascontiguousarray(pair)).to(dev)
+        self.empty_key = torch.from_numpy(empty).to(dev)
+        self._build()
+        return self
+
     def set_labels(self, rid_label):
         lab = np.asarray(rid_label, dtype=np.int32)
         if lab.shape != (self.num_roads,):
@@ -242,6 +287,9 @@ class GraphTables(object):
         g.n_roads, g.max_degree = self.num_roads, self.max_degree
         g.indptr, g.indices, g.geo = _lib.ptr(self.indptr), _lib.ptr(self.indices), _lib.ptr(self.geo)
         g.cost, g.label = _lib.ptr(self.cost), _lib.ptr(self.label)
+        g.dist_table = _lib.ptr(getattr(self, 'dist_table', None))
+        g.pair_cost = _lib.ptr(getattr(self, 'pair_cost', None))
+        g.empty_key = _lib.ptr(getattr(self, 'empty_key', None))
         self.c_graph = g
 
 
@@ -320,7 +368,7 @@ class AStarEngine(object):
         def dv(a):
             if torch.is_tensor(a):
                 return a.to(dev).to(i32).contiguous()
-            return torch.from_numpy(np.ascontiguousarray(np.asarray(a, dtype=np.int32))).to(dev)
+            return torch.from_numpy(np.array(a, dtype=np.int32, copy=True)).to(dev)
         prefix_ptr, prefix_rid, prefix_time = dv(prefix_ptr), dv(prefix_rid), dv(prefix_time)
         des, default_len, max_step_t = dv(des), dv(default_len), dv(max_step)
         n_od = int(des.numel())

@@ -79,7 +79,7 @@ class Searcher(object):
             np.cumsum(lens, out=prefix_ptr[1:])
             prefix_rid = np.concatenate([np.asarray(p[0], dtype=np.int32) for p in prefixes])
             prefix_time = np.concatenate([np.asarray(p[1], dtype=np.int32) for p in prefixes])
-            max_prefix = int(lens.max())
+            max_prefix = (int(lens.max()) + 63) // 64 * 64
         ms = np.broadcast_to(np.asarray(max_step, dtype=np.int32), (n_od,)).copy()
         ms_cap = int(ms.max()) if n_od else 1
         tables = gen_model.tables()
@@ -136,3 +136,168 @@ class Searcher(object):
             self.graph().set_labels(lab)
             self._label_key = key
         return self._single(gen_model, trace_loc, trace_tim, des, default_len, max_step, allow_label=[1])
+
+
+class DoubleLayerSearcher(object):
+    """Two-stage search (reference: search.py:821-934): region-level A* first (search.py:936-1117), then
+    road-level A* inside each region of the region path towards a border road drawn from the transfer
+    frequencies (:897-902), then the last leg to the destination (:925-931).
+
+    `astar_search` keeps the reference's one-OD signature and return value; `generate` runs many OD pairs:
+    one batched region search, then rounds of batched road legs (every unfinished OD submits its current
+    attempt).  The border-road order of an OD is drawn from its own `RandomState(seed)` (the reference uses
+    the global numpy RNG once per OD in sequence; seeding per OD is what makes a batch reproducible)."""
+
+    def __init__(self, device, adjacent_list, road_center_gps, road_length,
+                 region_adjacent_list, region_dist, region_transfer_freq,
+                 rid2region, region2rid, road_time_distribution, region_time_distribution):
+        self.device = torch.device(device)
+        self.adjacent_list = adjacent_list
+        self.road_center_gps = road_center_gps
+        self.road_length = road_length
+        self.region_adjacent_list = region_adjacent_list
+        self.region_dist = region_dist
+        self.region_transfer_freq = region_transfer_freq
+        self.rid2region = rid2region
+        self.region2rid = region2rid
+        self.region_time_distribution = region_time_distribution.astype(int)
+        self.road_search = Searcher(device, adjacent_list, road_center_gps, road_length, road_time_distribution)
+        self.fail_find_log = set()
+        self.region_fail_find_log = set()
+        self._region_search = None
+        self._labelled = False
+        self.last_stats = {}
+
+    # -- device substrate ------------------------------------------------------------------------
+    def _regions(self):
+        if self._region_search is None:
+            s = Searcher.__new__(Searcher)
+            s.device = self.device
+            s._graph = GraphTables.for_regions(self.device, self.region_adjacent_list, self.region_dist,
+                                               self.region_time_distribution, len(self.region2rid))
+            s._engines = {}
+            s._label_key = None
+            self._region_search = s
+        return self._region_search
+
+    def _label_roads(self):
+        if not self._labelled:
+            g = self.road_search.graph()
+            lab = np.full(g.num_roads, -1, dtype=np.int32)
+            for reg, rids in self.region2rid.items():           # region_rid_set = set(region2rid[str(region)])
+                lab[np.asarray(rids, dtype=np.int64)] = int(reg)
+            g.set_labels(lab)
+            self.road_search._label_key = 'regions'
+            self._labelled = True
+
+    # -- region stage ----------------------------------------------------------------------------
+    def _region_paths(self, region_model, start_regions, start_times, des_regions, max_step):
+        n = len(des_regions)
+        res = self._regions().generate(region_model, start_regions, start_times, des_regions,
+                                       np.full(n, 10, dtype=np.int32),      # best_default_len = 10 (search.py:967)
+                                       max_step=max_step, lmax=max(64, int(np.max(max_step)) + 2))
+        traces, flags = [], []
+        for i in range(n):
+            if (int(res['status'][i]) & 0xff) == STATUS_UNTOUCHED:
+                raise AssertionError('region search produced no trace (search.py:1113)')
+            k = int(res['len'][i])
+            tr = res['rid'][i, :k].tolist()
+            traces.append(tr)
+            flags.append(1 if tr[-1] == int(des_regions[i]) else 0)         # search.py:1114-1117
+        return traces, flags
+
+    def astar_search_in_region(self, region_model, start_region, start_time, des_region, max_step=500):
+        tr, fl = self._region_paths(region_model, [start_region], [start_time], [des_region],
+                                    np.asarray([max_step], dtype=np.int32))
+        return tr[0], fl[0]
+
+    # -- batched two-stage generation ------------------------------------------------------------
+    @torch.no_grad()
+    def generate(self, region_model, road_model, start_rids, start_times, des_rids, default_lens, max_step=500,
+                 seeds=None, rngs=None, slots=None):
+        """Returns (list of trace_loc, list of trace_tim, list of is_astar)."""
+        n = len(des_rids)
+        ms = np.broadcast_to(np.asarray(max_step, dtype=np.int32), (n,)).copy()
+        if rngs is None:
+            rngs = [np.random.RandomState(int(seeds[i]) if seeds is not None else i) for i in range(n)]
+        self._label_roads()
+        sreg = [self.rid2region[str(int(r))] for r in start_rids]
+        dreg = [self.rid2region[str(int(r))] for r in des_rids]
+        region_traces, is_astar = self._region_paths(region_model, sreg, start_times, dreg, ms)
+        for i in range(n):
+            if is_astar[i] != 1:
+                self.region_fail_find_log.add((sreg[i], dreg[i]))
+        loc = [[int(start_rids[i])] for i in range(n)]
+        tim = [[int(start_times[i])] for i in range(n)]
+        leg = [0] * n              # index into the region path
+        order = [None] * n         # border roads of the current region pair, in the drawn order
+        attempt = [0] * n
+        done = [False] * n
+        rounds = expansions = 0
+        while True:
+            act = [i for i in range(n) if not done[i]]
+            if not act:
+                break
+            targets, allow = [], []
+            for i in act:
+                rt = region_traces[i]
+                if leg[i] < len(rt) - 1:
+                    if order[i] is None:
+                        b = self.region_transfer_freq[str(rt[leg[i]])][str(rt[leg[i] + 1])]
+                        freq = np.array(b['transfer_freq'])
+                        order[i] = rngs[i].choice(b['transfer_rid'], len(b['transfer_rid']),
+                                                  p=freq / np.sum(freq), replace=False)      # search.py:900-902
+                        attempt[i] = 0
+                    targets.append(int(order[i][attempt[i]]))
+                    allow.append(int(rt[leg[i]]))
+                else:
+                    des = int(des_rids[i])
+                    in_last = self.road_search.graph().label is not None and \
+                        int(self.road_search.graph().label[des]) == int(rt[-1])
+                    targets.append(des)
+                    allow.append(int(rt[-1]) if in_last else -1)                             # search.py:925-931
+            pref = [(loc[i], tim[i]) for i in act]
+            lmax = max(256, max(len(p[0]) for p in pref) + 64, int(max(default_lens[i] for i in act)) + 1)
+            lmax = (lmax + 255) // 256 * 256
+            res = self.road_search.generate(road_model, None, None, targets, [int(default_lens[i]) for i in act],
+                                            max_step=ms[act], prefixes=pref, allow_label=allow, slots=slots,
+                                            lmax=lmax)
+            expansions += self.road_search.last_stats.get('expansions', 0)
+            rounds += 1
+            for j, i in enumerate(act):
+                k = int(res['len'][j])
+                if (int(res['status'][j]) & _lib.STATUS_OVERFLOW) or k > res['rid'].shape[1]:
+                    raise RuntimeError('trajectory longer than the output row')
+                loc[i] = res['rid'][j, :k].tolist()
+                tim[i] = res['time'][j, :k].tolist()
+                rt = region_traces[i]
+                if leg[i] < len(rt) - 1:
+                    if loc[i][-1] == targets[j]:                         # search.py:912-914
+                        leg[i] += 1
+                        order[i] = None
+                    else:
+                        self.fail_find_log.add((loc[i][-1], targets[j]))  # search.py:917
+                        attempt[i] += 1
+                        if attempt[i] >= len(order[i]):
+                            done[i] = True                                # search.py:918-919
+                else:
+                    if loc[i][-1] != int(des_rids[i]):
+                        self.fail_find_log.add((loc[i][-1], int(des_rids[i])))   # search.py:932-933
+                    done[i] = True
+        self.last_stats = {'rounds': rounds, 'road_expansions': expansions}
+        return loc, tim, is_astar
+
+    def astar_search(self, region_model, road_model, start_rid, start_tim, des, default_len, max_step=500):
+        class _GlobalRng(object):      # the reference draws from the global numpy RNG (search.py:900)
+            choice = staticmethod(np.random.choice)
+        loc, tim, fl = self.generate(region_model, road_model, [start_rid], [start_tim], [des], [default_len],
+                                     max_step=max_step, rngs=[_GlobalRng()], slots=1)
+        return loc[0], tim[0], fl[0]
+
+    def save_fail_log(self):
+        """search.py:1258-1269: ./log/find_error_log.json and ./log/region_find_error_log.json."""
+        os.makedirs('./log', exist_ok=True)
+        with open('./log/find_error_log.json', 'w') as f:
+            json.dump([[int(a), int(b)] for a, b in self.fail_find_log], f)
+        with open('./log/region_find_error_log.json', 'w') as f:
+            json.dump([[int(a), int(b)] for a, b in self.region_fail_find_log], f)
