@@ -129,7 +129,7 @@ struct LstmArgs {
 
 template <bool LAYER0>
 __global__ __launch_bounds__(256, 2) void lstm_layer_kernel(LstmArgs a) {
-  __shared__ TileLds t;
+  __shared__ TileLds tt[2];  // double-buffered k-tiles: one barrier per tile
   __shared__ long long s_prev[BM];
   __shared__ long long s_out[BM];
   __shared__ int s_rid[BM];
@@ -219,13 +219,13 @@ __global__ __launch_bounds__(256, 2) void lstm_layer_kernel(LstmArgs a) {
   RB = *reinterpret_cast<const float4*>(a.wt + (size_t)(k0 + b_kr + 8 * P) * ldw + coltile * BN + b_cc);
 #define TSG_LSTORE_A(P, RA, AM)                                              \
   {                                                                          \
-    float* dst = &t.a[a_r + 32 * P][a_kc];                                   \
+    float* dst = &tt[buf].a[a_r + 32 * P][a_kc];                                   \
     dst[0] = __uint_as_float(__float_as_uint(RA.x) & AM);                    \
     dst[1] = __uint_as_float(__float_as_uint(RA.y) & AM);                    \
     dst[2] = __uint_as_float(__float_as_uint(RA.z) & AM);                    \
     dst[3] = __uint_as_float(__float_as_uint(RA.w) & AM);                    \
   }
-#define TSG_LSTORE_B(P, RB) *reinterpret_cast<float4*>(&t.b[b_kr + 8 * P][b_cc]) = RB;
+#define TSG_LSTORE_B(P, RB) *reinterpret_cast<float4*>(&tt[buf].b[b_kr + 8 * P][b_cc]) = RB;
   auto gload = [&](int k0) {
     const bool below = !LAYER0 && (k0 < hp);
     const int kcol = below ? k0 : (!LAYER0 ? k0 - hp : k0);
@@ -233,26 +233,23 @@ __global__ __launch_bounds__(256, 2) void lstm_layer_kernel(LstmArgs a) {
     TSG_GLOAD_A(0, ra0, am0) TSG_GLOAD_A(1, ra1, am1) TSG_GLOAD_A(2, ra2, am2) TSG_GLOAD_A(3, ra3, am3)
     TSG_GLOAD_B(0, rb0) TSG_GLOAD_B(1, rb1) TSG_GLOAD_B(2, rb2) TSG_GLOAD_B(3, rb3)
   };
-  auto lstore = [&]() {
+  auto lstore = [&](int buf) {
     TSG_LSTORE_A(0, ra0, am0) TSG_LSTORE_A(1, ra1, am1) TSG_LSTORE_A(2, ra2, am2) TSG_LSTORE_A(3, ra3, am3)
     TSG_LSTORE_B(0, rb0) TSG_LSTORE_B(1, rb1) TSG_LSTORE_B(2, rb2) TSG_LSTORE_B(3, rb3)
   };
   gload(0);
-  lstore();
+  lstore(0);
   __syncthreads();
-  for (int k0 = 0; k0 < K; k0 += BK) {
+  for (int k0 = 0, cur = 0; k0 < K; k0 += BK, cur ^= 1) {
 #if TSG_ABLATE >= 11
     const bool more = false;
 #else
     const bool more = k0 + BK < K;
 #endif
     if (more) gload(k0 + BK);
-    mma_tile(t, wave, lane, acc);
+    mma_tile(tt[cur], wave, lane, acc);
+    if (more) lstore(cur ^ 1);  // the other buffer was last read before the previous barrier
     __syncthreads();
-    if (more) {
-      lstore();
-      __syncthreads();
-    }
   }
   // fused cell update: lane holds i,f,g,o of (row, unit) in acc[0..3][i].  Layer 0 still owes the time
   // term tproj[tcode] (an 11 MB, cache-resident table): fetched here four rows ahead of its use.
