@@ -1,7 +1,7 @@
 #!/bin/bash
 # timing-only ablation builds of the scoring kernel (outputs are wrong on purpose)
 for a in ${ABL:-1 2 3}; do
-  TSG_LIB_OVERRIDE=$PWD/ablate/libtsg_ab$a.so timeout -k 10 200 python -u bench.py --ods 16384 --warmup 0 --cpu-seconds 0 --streams 1 > gpurun_out/ab$a.log 2>&1 || exit 1
+  TSG_LIB_OVERRIDE=$PWD/ablate/libtsg_ab$a.so timeout -k 10 200 python -u bench.py --ods 32768 --warmup 1 --cpu-seconds 0 --streams 1 > gpurun_out/ab$a.log 2>&1 || exit 1
   python - <<PY
 import json
 l=[x for x in open('gpurun_out/ab$a.log') if x.startswith('{')][-1]

@@ -216,17 +216,20 @@ typedef struct tsg_engine {
   int32_t node_cap;  /* discovered nodes per slot (<= 2^20 - 1) */
   int32_t heap_cap;  /* heap entries per slot */
   /* workspaces (caller-allocated); *_bytes are checked against the dims above */
-  int32_t* slot_state;  size_t slot_state_bytes;  /* [B][32] int32 */
+  int32_t* slot_state;  size_t slot_state_bytes;  /* [B][40] int32 */
   uint64_t* heap;       size_t heap_bytes;        /* [B][heap_cap] {float prio; int32 node} */
   uint32_t* table;      size_t table_bytes;       /* [B][n_roads] rid -> (generation<<20 | node+1), zeroed by caller */
   int32_t* nodes;       size_t nodes_bytes;       /* [B][node_cap][8] int32 */
   int32_t* exp_meta;    size_t exp_meta_bytes;    /* [B][exp_cap][4] {parent, rid, tcode, depth} */
   int32_t* exp_up;      size_t exp_up_bytes;      /* [B][exp_cap][up_levels]: 2^k-th ancestor slot (binary lifting) */
-  int32_t up_levels;    int32_t reserved0;        /* must be TSG_UP_LEVELS */
+  int32_t up_levels;    float prune_spread;       /* |1-w1| + |w1| of the model (0 = only the all-closed rule): bound used to
+                                                     skip expansions that cannot push anything, see tsg_search.hip */
+  /* up_levels must be TSG_UP_LEVELS */
   float* h[TSG_MAX_LAYERS];                       /* [B*exp_cap][Hp] per layer */
   float* c[TSG_MAX_LAYERS];
   size_t state_bytes;                             /* bytes of EACH h[l] / c[l] */
-  int32_t* items;       size_t items_bytes;       /* [B][8] work items of the current superstep */
+  int32_t* items;       size_t items_bytes;       /* [B][8] work item of each search for the current superstep
+                                                     (word 0 = slot, or -1 when the search emitted none) */
   float* cand_lp;       size_t cand_lp_bytes;     /* [B][max_degree] */
   int32_t* shared_counters;                       /* [16] words 2,3,4,6 below; == counters for a lone engine.  Several
                                                      engines (disjoint workspaces, one HIP stream each) that work on

@@ -44,7 +44,7 @@ enum {
   SS_PHASE = 0, SS_OD, SS_STEP, SS_HEAP_N, SS_NODE_N, SS_EXP_N, SS_GEN, SS_WOFF, SS_DES, SS_DEFLEN,
   SS_MAXSTEP, SS_ALLOW, SS_WARM_K, SS_PLEN, SS_CUR_EXP, SS_CUR_RID, SS_CUR_C, SS_CUR_DATE_TIME,
   SS_CUR_LP, SS_BEST_LP, SS_BEST_PARENT, SS_BEST_RID, SS_BEST_TCODE, SS_HAVE_BEST, SS_NPOP, SS_POFF,
-  SS_CUR_DEPTH, SS_ST_EVALS, SS_ST_CAND, SS_ST_CHAIN, SS_CUR_COST, SS_WORDS = 32
+  SS_CUR_DEPTH, SS_ST_EVALS, SS_ST_CAND, SS_ST_CHAIN, SS_CUR_COST, SS_ST_SKIPPED, SS_ST_ITEMS, SS_WORDS = 40
 };
 enum { PH_IDLE = 0, PH_WARMUP = 1, PH_SEARCH = 2, PH_EXPANDED = 3, PH_DONE = 4 };
 // counters

@@ -144,6 +144,9 @@ __global__ __launch_bounds__(256, 2) void lstm_layer_kernel(LstmArgs a) {
   const int coltile = within % ct_n;
   const int row0 = rowtile * BM;
   if (row0 >= n) return;
+#if TSG_ABLATE == 21
+  return;
+#endif
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   if (tid < BM) {
     const int m = row0 + tid;
@@ -152,11 +155,13 @@ __global__ __launch_bounds__(256, 2) void lstm_layer_kernel(LstmArgs a) {
     if (m < n) {
       if (a.items) {
         const int32_t* it = a.items + (size_t)m * IT_WORDS;
-        const long long base = (long long)it[IT_SLOT] * a.exp_cap;
-        pv = it[IT_PARENT] >= 0 ? base + it[IT_PARENT] : -1;
-        ov = base + it[IT_EXP];
-        rd = it[IT_RID];
-        tc = it[IT_TCODE];
+        if (it[IT_SLOT] >= 0) {  // a search without a work item this superstep leaves its row inert
+          const long long base = (long long)it[IT_SLOT] * a.exp_cap;
+          pv = it[IT_PARENT] >= 0 ? base + it[IT_PARENT] : -1;
+          ov = base + it[IT_EXP];
+          rd = it[IT_RID];
+          tc = it[IT_TCODE];
+        }
       } else {
         pv = a.prev_idx[m];
         ov = a.out_idx[m];
@@ -240,7 +245,11 @@ __global__ __launch_bounds__(256, 2) void lstm_layer_kernel(LstmArgs a) {
   gload(0);
   lstore(0);
   __syncthreads();
+#if TSG_ABLATE == 22
+  for (int k0 = 0, cur = 0; k0 < BK; k0 += BK, cur ^= 1) {
+#else
   for (int k0 = 0, cur = 0; k0 < K; k0 += BK, cur ^= 1) {
+#endif
 #if TSG_ABLATE >= 11
     const bool more = false;
 #else
@@ -276,7 +285,7 @@ __global__ __launch_bounds__(256, 2) void lstm_layer_kernel(LstmArgs a) {
     const float cp = s_prev[r] >= 0 ? cprev[i] : 0.0f;
     const float cn = tsg_sigmoid(zf) * cp + tsg_sigmoid(zi) * tsg_tanh(zg);
     const float hn = tsg_sigmoid(zo) * tsg_tanh(cn);
-    if (row0 + r >= n) continue;
+    if (row0 + r >= n || s_out[r] < 0) continue;
     const size_t o = (size_t)s_out[r] * hp + u;
 #if TSG_ABLATE >= 13
     if (cn == 12345.0f) a.c[o] = hn;

@@ -95,14 +95,13 @@ struct EngineDev {
 // (search.py:355-356) into cand_lp[slot][c], where the scoring kernel picks it up and overwrites it with
 // the candidate's log-probability.
 __global__ __launch_bounds__(256) void cand_dis_kernel(EngineDev D, int superstep) {
-  const int n_items = D.e.counters[superstep & 1];
   const int md = D.g.max_degree;
   const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const int idx = (int)(t / md), c = (int)(t % md);
-  if (idx >= n_items) return;
-  const int32_t* it = D.e.items + (size_t)idx * IT_WORDS;
+  if (idx >= D.e.slots) return;
+  const int32_t* it = D.e.items + (size_t)idx * IT_WORDS;  // items are indexed by slot
   const int ncand = it[IT_NCAND];
-  if (ncand < 2 || c >= ncand) return;
+  if (it[IT_SLOT] < 0 || ncand < 2 || c >= ncand) return;
   const int cand = D.g.indices[D.g.indptr[it[IT_RID]] + c];
   float dis;
   if (D.g.dist_table) {  // region graphs: region_dist[c][des] / 100 (search.py:1049)
@@ -122,14 +121,9 @@ template <int JT>
 __global__ __launch_bounds__(256) void score_frontier_kernel(tsg_model m, EngineDev D, int superstep) {
   const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
-  int32_t* counters = D.e.counters;
-  const int n_items = counters[superstep & 1];
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    counters[(superstep + 1) & 1] = 0;  // next superstep's item counter
-    atomicAdd(&counters[CT_ITEMS_TOTAL], n_items);
-  }
-  if (idx >= n_items) return;
-  const int32_t* it = D.e.items + (size_t)idx * IT_WORDS;
+  if (idx >= D.e.slots) return;
+  const int32_t* it = D.e.items + (size_t)idx * IT_WORDS;  // items are indexed by slot
+  if (it[IT_SLOT] < 0) return;                               // this search emitted nothing (finished batch)
   const int ncand = it[IT_NCAND];
   const int b = it[IT_SLOT], e = it[IT_EXP];
   constexpr int LV = TSG_UP_LEVELS;  // levels 0..5 resolve a lane's ancestor inside a 64-chunk, level 6 hops chunks
@@ -239,6 +233,31 @@ struct HeapEnt {
   int node;
 };
 
+#ifndef TSG_STAMP
+#define TSG_STAMP 0  // diagnostic build only: cycle shares of the frontier kernel's phases (never shipped)
+#endif
+#if TSG_STAMP
+__device__ unsigned long long g_stamp[16];
+#define CKPT(i)                         \
+  {                                     \
+    const long long _n = clock64();     \
+    st_acc[i] += _n - st_last;          \
+    st_last = _n;                       \
+  }
+#define STAMP_ADD(i, v) st_acc[i] += (long long)(v)
+extern "C" int tsg_debug_read_stamps(unsigned long long* out_host, int reset) {
+  if (hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_stamp), sizeof(g_stamp)) != hipSuccess) return -1;
+  if (reset) {
+    unsigned long long z[16] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamp), z, sizeof(z)) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#else
+#define CKPT(i)
+#define STAMP_ADD(i, v)
+#endif
+
 __device__ __forceinline__ HeapEnt heap_ld(const uint64_t* h, int i) {
   const uint64_t v = h[i];
   HeapEnt e;
@@ -257,38 +276,84 @@ __device__ __forceinline__ bool ent_less(HeapEnt a, HeapEnt b, const int32_t* no
   return __int_as_float(nodes[(size_t)a.node * ND_WORDS + ND_LP]) <
          __int_as_float(nodes[(size_t)b.node * ND_WORDS + ND_LP]);
 }
-// heapq.heappush == append + _siftdown(heap, 0, len-1)
+__device__ __forceinline__ HeapEnt ent_of(uint64_t v) {
+  HeapEnt e;
+  e.prio = __uint_as_float((uint32_t)v);
+  e.node = (int)(v >> 32);
+  return e;
+}
+// heapq.heappush == append + _siftdown(heap, 0, len-1).  The ancestors of the insertion point have known
+// addresses, so four of them are fetched per round trip instead of one.
 __device__ __forceinline__ void heap_push(uint64_t* h, int& n, HeapEnt item, const int32_t* nodes) {
   int pos = n++;
   while (pos > 0) {
-    const int pp = (pos - 1) >> 1;
-    const HeapEnt par = heap_ld(h, pp);
-    if (!ent_less(item, par, nodes)) break;
-    heap_st(h, pos, par);
-    pos = pp;
+    int ai[4];
+    uint64_t av[4];
+    int p = pos;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      p = p > 0 ? (p - 1) >> 1 : 0;
+      ai[k] = p;
+      av[k] = h[p];
+    }
+    bool stop = false;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (stop || pos == 0) continue;
+      const HeapEnt par = ent_of(av[k]);
+      if (!ent_less(item, par, nodes)) {
+        stop = true;
+      } else {
+        heap_st(h, pos, par);
+        pos = ai[k];
+      }
+    }
+    if (stop) break;
   }
   heap_st(h, pos, item);
 }
-// heapq.heappop == pop last, put it at the root, _siftup (bubble smaller child up to a leaf, then _siftdown)
+// heapq.heappop == pop last, put it at the root, _siftup (bubble the smaller child up to a leaf, then
+// _siftdown).  Three levels below the current position (2 + 4 + 8 entries, contiguous per level) are
+// fetched per round trip; the decisions are the same comparisons in the same order.
 __device__ __forceinline__ HeapEnt heap_pop(uint64_t* h, int& n, const int32_t* nodes) {
   const HeapEnt last = heap_ld(h, n - 1);
   --n;
   if (n == 0) return last;
   const HeapEnt ret = heap_ld(h, 0);
-  int pos = 0, child = 1;
-  while (child < n) {
-    const int right = child + 1;
-    HeapEnt ce = heap_ld(h, child);
-    if (right < n) {
-      const HeapEnt re = heap_ld(h, right);
-      if (!ent_less(ce, re, nodes)) {
-        child = right;
-        ce = re;
-      }
-    }
-    heap_st(h, pos, ce);
-    pos = child;
+  const int hi = n - 1;
+  int pos = 0;
+  while (2 * pos + 1 < n) {
+    const int c0 = 2 * pos + 1, g0 = 4 * pos + 3, q0 = 8 * pos + 7;
+    uint64_t cv[2], gv[4], qv[8];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) cv[i] = h[c0 + i < hi ? c0 + i : hi];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) gv[i] = h[g0 + i < hi ? g0 + i : hi];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) qv[i] = h[q0 + i < hi ? q0 + i : hi];
+    // level 1
+    int s1 = 0;
+    if (c0 + 1 < n && !ent_less(ent_of(cv[0]), ent_of(cv[1]), nodes)) s1 = 1;
+    h[pos] = cv[s1];
+    pos = c0 + s1;
+    int child = 2 * pos + 1;
+    if (child >= n) break;
+    // level 2
+    const uint64_t gl = s1 ? gv[2] : gv[0], gr = s1 ? gv[3] : gv[1];
+    int s2 = 0;
+    if (child + 1 < n && !ent_less(ent_of(gl), ent_of(gr), nodes)) s2 = 1;
+    h[pos] = s2 ? gr : gl;
+    pos = child + s2;
     child = 2 * pos + 1;
+    if (child >= n) break;
+    // level 3
+    const int sel = 2 * s1 + s2;
+    const uint64_t ql = sel == 0 ? qv[0] : sel == 1 ? qv[2] : sel == 2 ? qv[4] : qv[6];
+    const uint64_t qr = sel == 0 ? qv[1] : sel == 1 ? qv[3] : sel == 2 ? qv[5] : qv[7];
+    int s3 = 0;
+    if (child + 1 < n && !ent_less(ent_of(ql), ent_of(qr), nodes)) s3 = 1;
+    h[pos] = s3 ? qr : ql;
+    pos = child + s3;
   }
   while (pos > 0) {
     const int pp = (pos - 1) >> 1;
@@ -301,16 +366,21 @@ __device__ __forceinline__ HeapEnt heap_pop(uint64_t* h, int& n, const int32_t* 
   return ret;
 }
 
-__global__ __launch_bounds__(64) void frontier_kernel(EngineDev D, int superstep) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= D.e.slots) return;
+// TSG_SPW searches per wave (one lane each, the other lanes idle): the work is a chain of dependent small
+// accesses, so what matters is how many chains are in flight and how long a search waits for the slowest
+// search of its wave (every divergent loop runs to the longest trip count in the wave), not lane use.
+#ifndef TSG_SPW
+#define TSG_SPW 4
+#endif
+__global__ __launch_bounds__(256) void frontier_kernel(EngineDev D, int superstep) {
+  const int b = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * TSG_SPW + (threadIdx.x & 63);
+  if (b >= D.e.slots || (threadIdx.x & 63) >= TSG_SPW) return;
   int32_t* S = D.e.slot_state + (size_t)b * SS_WORDS;
   int phase = S[SS_PHASE];
   if (phase == PH_DONE) return;
   const tsg_graph& g = D.g;
   const tsg_od_batch& od = D.od;
-  int32_t* counters = D.e.counters;
-  int32_t* item_cnt = &counters[superstep & 1];
+  int32_t* my_item = D.e.items + (size_t)b * IT_WORDS;  // one work item per search and superstep, indexed by slot
   int32_t* shared = D.e.shared_counters;  // OD queue + completion, common to all sub-engines of a batch
   uint64_t* heap = D.e.heap + (size_t)b * D.e.heap_cap;
   uint32_t* table = D.e.table + (size_t)b * g.n_roads;
@@ -325,6 +395,10 @@ __global__ __launch_bounds__(64) void frontier_kernel(EngineDev D, int superstep
   int have_best = S[SS_HAVE_BEST], npop = S[SS_NPOP];
   int err = 0;
 
+#if TSG_STAMP
+  long long st_acc[16] = {0};
+  long long st_last = clock64();
+#endif
   // ---- relax the expansion scored during the previous superstep (search.py:385-419 / 317-350)
   if (phase == PH_EXPANDED) {
     const int e = S[SS_CUR_EXP], C = S[SS_CUR_C], rid = S[SS_CUR_RID];
@@ -332,73 +406,115 @@ __global__ __launch_bounds__(64) void frontier_kernel(EngineDev D, int superstep
     const float lp_parent = __int_as_float(S[SS_CUR_LP]);
     const int child_depth = S[SS_CUR_DEPTH] + 1;
     const int base = g.indptr[rid];
-    for (int i = 0; i < C; ++i) {
-      const int c = g.indices[base + i];
-      const float lp = (C == 1) ? lp_parent : D.e.cand_lp[(size_t)b * g.max_degree + i];
-      // travel time of the expanded road (search.py:376-382); region graphs fall back to a per-pair
-      // cost when the region's time distribution is unknown (search.py:1073-1078)
-      const int cost = cur_cost >= 0 ? cur_cost : g.pair_cost[(size_t)rid * g.n_roads + c];
-      const int next_time = (cur_date_time + cost) % 86400;
-      const int tcode_child = next_time / 60 + woff;
-      const uint32_t t = table[c];
-      bool pushed = false;
-      int idx = -1;
-      if ((int)(t >> TSG_GEN_SHIFT) != gen) {  // c not in rid2node and not in close_set
-        if (node_n >= D.e.node_cap || heap_n >= D.e.heap_cap) {
-          err = 1;
-          break;
-        }
-        idx = node_n++;
-        int32_t* nd = nodes + (size_t)idx * ND_WORDS;
-        nd[ND_RID] = c;
-        nd[ND_PARENT] = e;
-        nd[ND_LP] = __float_as_int(lp);
-        nd[ND_DATE_TIME] = next_time;
-        nd[ND_EXP] = ND_OPEN;
-        table[c] = ((uint32_t)gen << TSG_GEN_SHIFT) | (uint32_t)idx;
-        pushed = true;
-      } else {
-        idx = (int)(t & TSG_NODE_MASK);
-        int32_t* nd = nodes + (size_t)idx * ND_WORDS;
-        if (nd[ND_EXP] == ND_OPEN && __int_as_float(nd[ND_LP]) < lp) {  // c in rid2node, strictly better
-          if (heap_n >= D.e.heap_cap) {
-            err = 1;
-            break;
+    for (int i0 = 0; i0 < C && !err; i0 += 4) {
+      // the table entries and node records of up to four successors are fetched together; the pushes
+      // themselves stay in list order (search.py:385)
+      int cc[4];
+      float lps[4];
+      uint32_t tt[4];
+      int nexp[4];
+      float nlp[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int i = i0 + k < C ? i0 + k : C - 1;
+        cc[k] = g.indices[base + i];
+        lps[k] = (C == 1) ? lp_parent : D.e.cand_lp[(size_t)b * g.max_degree + i];
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) tt[k] = table[cc[k]];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const bool seen = (int)(tt[k] >> TSG_GEN_SHIFT) == gen;
+        const int32_t* nd = nodes + (size_t)(seen ? (tt[k] & TSG_NODE_MASK) : 0) * ND_WORDS;
+        nexp[k] = nd[ND_EXP];
+        nlp[k] = __int_as_float(nd[ND_LP]);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (i0 + k >= C || err) continue;
+        const int c = cc[k];
+        const float lp = lps[k];
+        bool dup = false;  // the same road twice in one list: re-read what the earlier entry may have changed
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (j < k && cc[j] == c) dup = true;
+        if (dup) {
+          tt[k] = table[c];
+          if ((int)(tt[k] >> TSG_GEN_SHIFT) == gen) {
+            const int32_t* nd = nodes + (size_t)(tt[k] & TSG_NODE_MASK) * ND_WORDS;
+            nexp[k] = nd[ND_EXP];
+            nlp[k] = __int_as_float(nd[ND_LP]);
           }
+        }
+        // travel time of the expanded road (search.py:376-382); region graphs fall back to a per-pair
+        // cost when the region's time distribution is unknown (search.py:1073-1078)
+        const int cost = cur_cost >= 0 ? cur_cost : g.pair_cost[(size_t)rid * g.n_roads + c];
+        const int next_time = (cur_date_time + cost) % 86400;
+        const int tcode_child = next_time / 60 + woff;
+        const uint32_t t = tt[k];
+        bool pushed = false;
+        int idx = -1;
+        if ((int)(t >> TSG_GEN_SHIFT) != gen) {  // c not in rid2node and not in close_set
+          if (node_n >= D.e.node_cap || heap_n >= D.e.heap_cap) {
+            err = 1;
+            continue;
+          }
+          idx = node_n++;
+          int32_t* nd = nodes + (size_t)idx * ND_WORDS;
+          nd[ND_RID] = c;
           nd[ND_PARENT] = e;
           nd[ND_LP] = __float_as_int(lp);
           nd[ND_DATE_TIME] = next_time;
+          nd[ND_EXP] = ND_OPEN;
+          table[c] = ((uint32_t)gen << TSG_GEN_SHIFT) | (uint32_t)idx;
           pushed = true;
+        } else {
+          idx = (int)(t & TSG_NODE_MASK);
+          if (nexp[k] == ND_OPEN && nlp[k] < lp) {  // c in rid2node, strictly better
+            if (heap_n >= D.e.heap_cap) {
+              err = 1;
+              continue;
+            }
+            int32_t* nd = nodes + (size_t)idx * ND_WORDS;
+            nd[ND_PARENT] = e;
+            nd[ND_LP] = __float_as_int(lp);
+            nd[ND_DATE_TIME] = next_time;
+            pushed = true;
+          }
         }
-      }
-      if (pushed) {
-        HeapEnt he;
-        he.prio = -lp;
-        he.node = idx;
-        heap_push(heap, heap_n, he, nodes);
-        // default-length fallback snapshot (search.py:397-402): np.exp(lp) > best_score, best_score starts at 0
-        if (child_depth == deflen && lp > best_lp && lp > -745.13f) {
-          best_lp = lp;
-          best_parent = e;
-          best_rid = c;
-          best_tcode = tcode_child;
-          have_best = 1;
+        if (pushed) {
+          HeapEnt he;
+          he.prio = -lp;
+          he.node = idx;
+          heap_push(heap, heap_n, he, nodes);
+          // default-length fallback snapshot (search.py:397-402): np.exp(lp) > best_score, best_score starts at 0
+          if (child_depth == deflen && lp > best_lp && lp > -745.13f) {
+            best_lp = lp;
+            best_parent = e;
+            best_rid = c;
+            best_tcode = tcode_child;
+            have_best = 1;
+          }
         }
       }
     }
     phase = PH_SEARCH;
   }
 
+  CKPT(0);
+  STAMP_ADD(7, 1);
   bool emitted = false;
   while (!emitted && !err) {
     if (phase == PH_IDLE) {
       if (gen >= TSG_GEN_MAX) {  // table generation space exhausted for this slot: stop refilling it
         phase = PH_DONE;
+        my_item[IT_SLOT] = -1;
         break;
       }
       odi = atomicAdd(&shared[CT_NEXT_OD], 1);
       if (odi >= od.n_od) {
         phase = PH_DONE;
+        my_item[IT_SLOT] = -1;
         break;
       }
       // ---- start a new search (search.py:255-278)
@@ -444,8 +560,7 @@ __global__ __launch_bounds__(64) void frontier_kernel(EngineDev D, int superstep
     }
     if (phase == PH_WARMUP) {  // run the recurrent cell over the known prefix, one element per superstep
       const int k = warm_k++;
-      const int slot = atomicAdd(item_cnt, 1);
-      int32_t* it = D.e.items + (size_t)slot * IT_WORDS;
+      int32_t* it = my_item;
       it[IT_SLOT] = b;
       it[IT_EXP] = k;
       it[IT_PARENT] = k - 1;
@@ -454,6 +569,7 @@ __global__ __launch_bounds__(64) void frontier_kernel(EngineDev D, int superstep
       it[IT_NCAND] = 0;
       it[IT_DES] = des;
       it[IT_LP] = 0;
+      S[SS_ST_ITEMS] += 1;
       if (warm_k >= plen - 1) phase = PH_SEARCH;
       emitted = true;
       break;
@@ -461,7 +577,10 @@ __global__ __launch_bounds__(64) void frontier_kernel(EngineDev D, int superstep
     // ---- PH_SEARCH: pop until a node can be expanded (search.py:279-300)
     int fin_status = -1, fin_parent = -1, fin_rid = -1, fin_tcode = 0, fin_depth = 0;
     while (heap_n > 0 && step < max_step) {
+      CKPT(6);
       const HeapEnt top = heap_pop(heap, heap_n, nodes);
+      CKPT(1);
+      STAMP_ADD(8, 1);
       int32_t* nd = nodes + (size_t)top.node * ND_WORDS;
       if (nd[ND_EXP] != ND_OPEN) continue;  // stale duplicate of a closed rid (search.py:284-287)
       const int rid = nd[ND_RID];
@@ -495,6 +614,44 @@ __global__ __launch_bounds__(64) void frontier_kernel(EngineDev D, int superstep
         nd[ND_EXP] = ND_CLOSED_NOSLOT;
         continue;
       }
+      CKPT(3);
+      {  // Expansions that cannot change anything.  The reference still evaluates the model (search.py:359-367)
+         // but pushes nothing when every successor is either closed (:388 fails, :403 needs rid2node) or open
+         // with a log_prob that no outcome of this evaluation can beat: f = softmax(mix) with every mix_c
+         // inside an interval of width s = |1-w1| + |w1| gives f_c <= e^s / (e^s + C - 1).  Nothing pushed
+         // means no child will ever need this node's recurrent state, so it is closed without an LSTM step
+         // or a scoring pass; results are unchanged.
+        const float lp_node = __int_as_float(nd[ND_LP]);
+        float ub = lp_node;  // C == 1: the child inherits the log_prob (search.py:305)
+        bool use_bound = C == 1;
+        if (C > 1 && D.e.prune_spread > 0.0f) {
+          const float es = __expf(D.e.prune_spread);
+          ub = lp_node + logf(es / (es + (float)(C - 1))) + 1e-4f;
+          use_bound = true;
+        }
+        bool futile = true;
+        for (int i0 = 0; i0 < C && futile; i0 += 4) {
+          uint32_t tt[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) tt[k] = table[g.indices[beg + (i0 + k < C ? i0 + k : C - 1)]];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const bool seen = (int)(tt[k] >> TSG_GEN_SHIFT) == gen;
+            const int32_t* q = nodes + (size_t)(seen ? (tt[k] & TSG_NODE_MASK) : 0) * ND_WORDS;
+            const int qexp = q[ND_EXP];
+            const float qlp = __int_as_float(q[ND_LP]);
+            const bool dead = seen && (qexp != ND_OPEN || (use_bound && qlp >= ub));
+            if (!dead) futile = false;
+          }
+        }
+        if (futile) {
+          nd[ND_EXP] = ND_CLOSED_NOSLOT;
+          S[SS_ST_SKIPPED] += 1;
+          CKPT(9);
+          continue;
+        }
+      }
+      CKPT(4);
       if (exp_n >= D.e.exp_cap) {
         err = 1;
         break;
@@ -519,10 +676,10 @@ __global__ __launch_bounds__(64) void frontier_kernel(EngineDev D, int superstep
         S[SS_ST_CAND] += C;
         S[SS_ST_CHAIN] += depth;
       }
-      const int slot = atomicAdd(item_cnt, 1);
-      int32_t* it = D.e.items + (size_t)slot * IT_WORDS;
+      int32_t* it = my_item;
       it[IT_SLOT] = b;
       it[IT_EXP] = e;
+      S[SS_ST_ITEMS] += 1;
       it[IT_PARENT] = parent;
       it[IT_RID] = rid;
       it[IT_TCODE] = tcode;
@@ -531,9 +688,11 @@ __global__ __launch_bounds__(64) void frontier_kernel(EngineDev D, int superstep
       it[IT_LP] = nd[ND_LP];
       phase = PH_EXPANDED;
       emitted = true;
+      CKPT(5);
       break;
     }
     if (emitted || err) break;
+    CKPT(10);
     // ---- the search is over (search.py:421-424): destination popped, queue empty, or budget spent
     if (fin_status < 0) {
       if (have_best) {
@@ -578,10 +737,12 @@ __global__ __launch_bounds__(64) void frontier_kernel(EngineDev D, int superstep
       atomicAdd(&shared[CT_FINISHED], 1);
     }
     phase = PH_IDLE;
+    CKPT(11);
   }
   if (err) {
     // a workspace cap was hit: report, finish the OD as OVERFLOW so that the batch still terminates
     atomicExch(&shared[CT_ERROR], 1);
+    my_item[IT_SLOT] = -1;
     if (odi >= 0 && odi < od.n_od) {
       od.out_len[odi] = 0;
       od.out_status[odi] = TSG_STATUS_OVERFLOW;
@@ -590,6 +751,11 @@ __global__ __launch_bounds__(64) void frontier_kernel(EngineDev D, int superstep
     }
     phase = PH_IDLE;
   }
+  CKPT(2);
+#if TSG_STAMP
+  for (int i = 0; i < 16; ++i)
+    if (st_acc[i]) atomicAdd(&g_stamp[i], (unsigned long long)st_acc[i]);
+#endif
   S[SS_PHASE] = phase;
   S[SS_OD] = odi;
   S[SS_STEP] = step;
@@ -672,7 +838,7 @@ extern "C" int tsg_frontier_expand_select(const tsg_graph* g, const tsg_od_batch
   D.e = *e;
   D.g = *g;
   D.od = *od;
-  hipLaunchKernelGGL(frontier_kernel, dim3(tsg_cdiv(e->slots, 64)), dim3(64), 0, (hipStream_t)stream, D, superstep);
+  hipLaunchKernelGGL(frontier_kernel, dim3(tsg_cdiv(e->slots, 4 * TSG_SPW)), dim3(256), 0, (hipStream_t)stream, D, superstep);
   TSG_LAUNCH_CHECK();
   return 0;
 }
@@ -703,16 +869,15 @@ extern "C" int tsg_engine_run(const tsg_model* m, const tsg_graph* g, const tsg_
   D.e = *e;
   D.g = *g;
   D.od = *od;
-  const dim3 fgrid(tsg_cdiv(e->slots, 64));
+  const dim3 fgrid(tsg_cdiv(e->slots, 4 * TSG_SPW));
   for (int k = 0; k < n_supersteps; ++k) {
     const int ss = first_superstep + k;
-    hipLaunchKernelGGL(frontier_kernel, fgrid, dim3(64), 0, s, D, ss);
+    hipLaunchKernelGGL(frontier_kernel, fgrid, dim3(256), 0, s, D, ss);
     TSG_LAUNCH_CHECK();
     launch_cand_dis(D, ss, s);
     TSG_LAUNCH_CHECK();
-    const int32_t* n_items = e->counters + (ss & 1);
     for (int l = 0; l < m->n_layers; ++l) {
-      rc = tsg_launch_lstm_layer(m, l, e->slots, n_items, 0, nullptr, nullptr, nullptr, nullptr, e->items, e->exp_cap,
+      rc = tsg_launch_lstm_layer(m, l, e->slots, nullptr, e->slots, nullptr, nullptr, nullptr, nullptr, e->items, e->exp_cap,
                                  l > 0 ? e->h[l - 1] : nullptr, e->h[l], e->c[l], s);
       if (rc) return rc;
     }
@@ -746,19 +911,18 @@ extern "C" int tsg_engine_run_profiled(const tsg_model* m, const tsg_graph* g, c
       delete[] ev;
       return TSG_E_INVALID;
     }
-  const dim3 fgrid(tsg_cdiv(e->slots, 64));
+  const dim3 fgrid(tsg_cdiv(e->slots, 4 * TSG_SPW));
   int q = 0;
   rc = 0;
   for (int k = 0; k < n_supersteps && rc == 0; ++k) {
     const int ss = first_superstep + k;
     (void)hipEventRecord(ev[q++], s);
-    hipLaunchKernelGGL(frontier_kernel, fgrid, dim3(64), 0, s, D, ss);
+    hipLaunchKernelGGL(frontier_kernel, fgrid, dim3(256), 0, s, D, ss);
     launch_cand_dis(D, ss, s);  // timed with the frontier kernel
     (void)hipEventRecord(ev[q++], s);
-    const int32_t* n_items = e->counters + (ss & 1);
     for (int l = 0; l < m->n_layers && rc == 0; ++l) {
       (void)hipEventRecord(ev[q++], s);
-      rc = tsg_launch_lstm_layer(m, l, e->slots, n_items, 0, nullptr, nullptr, nullptr, nullptr, e->items, e->exp_cap,
+      rc = tsg_launch_lstm_layer(m, l, e->slots, nullptr, e->slots, nullptr, nullptr, nullptr, nullptr, e->items, e->exp_cap,
                                  l > 0 ? e->h[l - 1] : nullptr, e->h[l], e->c[l], s);
       (void)hipEventRecord(ev[q++], s);
     }

@@ -300,7 +300,7 @@ class AStarEngine(object):
     while one sub-engine is in its latency-bound frontier / scoring kernels, another keeps the matrix cores
     busy with its LSTM step.  Workspaces are disjoint slices of the same tensors."""
 
-    def __init__(self, tables, graph, slots, max_step, max_prefix=1, lmax=256, streams=1):
+    def __init__(self, tables, graph, slots, max_step, max_prefix=1, lmax=256, streams=1, prune=True):
         self.tables, self.graph = tables, graph
         dev = self.device = tables.device
         n = graph.num_roads
@@ -316,12 +316,14 @@ class AStarEngine(object):
             raise ValueError('node_cap %d exceeds 2^20-1' % self.node_cap)
         hp, nl = tables.hp, tables.n_layers
         i32, f32 = torch.int32, torch.float32
-        self.slot_state = torch.zeros((B, 32), dtype=i32, device=dev)
+        self.slot_state = torch.zeros((B, 40), dtype=i32, device=dev)
         self.heap = torch.empty((B, self.heap_cap), dtype=torch.int64, device=dev)
         self.table = torch.zeros((B, n), dtype=i32, device=dev)
         self.nodes = torch.empty((B, self.node_cap, 8), dtype=i32, device=dev)
         self.exp_meta = torch.empty((B, self.exp_cap, 4), dtype=i32, device=dev)
         self.up_levels = 8      # TSG_UP_LEVELS
+        w1 = float(tables.hparams[41])
+        self.prune_spread = (abs(1.0 - w1) + abs(w1)) * (1.0 + 1e-6) if prune else 0.0
         self.exp_up = torch.empty((B, self.exp_cap, self.up_levels), dtype=i32, device=dev)
         self.h = [torch.empty((B * self.exp_cap, hp), dtype=f32, device=dev) for _ in range(nl)]
         self.c = [torch.empty((B * self.exp_cap, hp), dtype=f32, device=dev) for _ in range(nl)]
@@ -342,6 +344,7 @@ class AStarEngine(object):
                 e.c[l] = self.c[l][k * sb * self.exp_cap:].data_ptr()
             e.state_bytes = sb * self.exp_cap * hp * 4
             e.up_levels = self.up_levels
+            e.prune_spread = self.prune_spread
             e.counters = self.counters[k].data_ptr()
             e.counters_bytes = 64
             e.shared_counters = self.counters[streams].data_ptr()
@@ -355,7 +358,7 @@ class AStarEngine(object):
         node_cap = min(graph.num_roads, 1 + max_step * graph.max_degree) + 1
         heap_cap = 1 + max_step * graph.max_degree
         return (2 * tables.n_layers * exp_cap * tables.hp * 4 + heap_cap * 8 + graph.num_roads * 4
-                + node_cap * 32 + exp_cap * (16 + 4 * 8) + 32 * 4 + 32 + graph.max_degree * 4)
+                + node_cap * 32 + exp_cap * (16 + 4 * 8) + 40 * 4 + 32 + graph.max_degree * 4)
 
     @torch.no_grad()
     def run(self, prefix_ptr, prefix_rid, prefix_time, des, default_len, max_step, allow_label=None,
@@ -440,13 +443,13 @@ class AStarEngine(object):
                     # sampled chunk: drain every stream, then time each sub-engine's kernels on their own
                     for s in streams:
                         s.synchronize()
-                    items0 = int(self.counters[:K, 7].sum())
+                    items0 = int(self.slot_state[:, 32].sum())
                     for k in range(K):
                         _lib.check(L.tsg_engine_run_profiled(C.byref(m), C.byref(g), C.byref(od),
                                                              C.byref(self.c_engines[k]), supersteps, chunk, handles[k],
                                                              prof_ms, prof_n), 'tsg_engine_run_profiled')
                     cnt = self.counters.cpu()
-                    prof_items += int(cnt[:K, 7].sum()) - items0
+                    prof_items += int(self.slot_state[:, 32].sum()) - items0
                 else:
                     for k in range(K):
                         if len(inflight[k]) >= 2:
@@ -478,8 +481,8 @@ class AStarEngine(object):
             raise RuntimeError('A* engine hit a workspace cap (node/heap/exp capacity)')
         st = self.slot_state.to(torch.int64).sum(dim=0).cpu()
         self.last_stats = {'supersteps': supersteps, 'expansions': int(cnt[K, 4]), 'model_evals': int(st[27]),
-                           'n_od': n_od, 'items': int(cnt[:K, 7].sum()),
-                           'chain_sum': int(st[29]), 'cand_sum': int(st[28]),
+                           'n_od': n_od, 'items': int(st[32]),
+                           'chain_sum': int(st[29]), 'cand_sum': int(st[28]), 'skipped_all_closed': int(st[31]),
                            'prof_ms': list(prof_ms), 'prof_launches': list(prof_n), 'prof_items': prof_items,
                            'sub_engines': K}
         res = {'rid': out_rid, 'time': out_time, 'len': out_len, 'status': out_status, 'steps': out_steps}
