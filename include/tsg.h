@@ -37,7 +37,7 @@ extern "C" {
 
 #define TSG_MAX_LAYERS 4
 #define TSG_MAX_DEGREE 64 /* successors per road the scoring kernel handles in one wave */
-#define TSG_UP_LEVELS 8   /* binary-lifting levels stored per expanded node (levels 0..6 are used) */
+#define TSG_UP_LEVELS 64  /* ancestors listed per expanded node (exp_up row width) */
 #define TSG_H_HIDDEN 10   /* emb_fc / dis_fc width, hard-coded at distance_gat_fc.py:38-40 */
 
 /* per-OD result status (mirrors the three exits of search.py:421-424) */
@@ -221,7 +221,7 @@ typedef struct tsg_engine {
   uint32_t* table;      size_t table_bytes;       /* [B][n_roads] rid -> (generation<<20 | node+1), zeroed by caller */
   int32_t* nodes;       size_t nodes_bytes;       /* [B][node_cap][8] int32 */
   int32_t* exp_meta;    size_t exp_meta_bytes;    /* [B][exp_cap][4] {parent, rid, tcode, depth} */
-  int32_t* exp_up;      size_t exp_up_bytes;      /* [B][exp_cap][up_levels]: 2^k-th ancestor slot (binary lifting) */
+  int32_t* exp_up;      size_t exp_up_bytes;      /* [B][exp_cap][64]: exp_up[e][i] = the (i+1)-th ancestor slot of e, -1 = none */
   int32_t up_levels;    float prune_spread;       /* |1-w1| + |w1| of the model (0 = only the all-closed rule): bound used to
                                                      skip expansions that cannot push anything, see tsg_search.hip */
   /* up_levels must be TSG_UP_LEVELS */

@@ -113,10 +113,11 @@ __global__ __launch_bounds__(256) void cand_dis_kernel(EngineDev D, int superste
   D.e.cand_lp[(size_t)it[IT_SLOT] * md + c] = dis;
 }
 
-// Ancestors are found through a binary-lifting table: up[e][k] = the 2^k-th ancestor of expanded
-// slot e (or -1).  A wave first writes the row of its own slot (one dependent load per level), then
-// lane t resolves the t-th ancestor in <= 6 dependent loads, so the key rows of the attention are
-// fetched as independent, fully coalesced row loads instead of a pointer chase.
+// Every expanded slot e keeps the list of its 64 nearest ancestors: anc[e][i] = the (i+1)-th ancestor
+// (or -1).  A wave builds the list of its own slot from its parent's list with ONE coalesced 256-byte read
+// (anc[e][0] = parent, anc[e][i] = anc[parent][i-1]) and then already holds, one per lane, the slots whose
+// top-layer hidden rows the attention needs: no pointer chase, the key rows are independent coalesced
+// loads.  Chains longer than 64 hop through anc[.][63] once per 64 rows.
 template <int JT>
 __global__ __launch_bounds__(256) void score_frontier_kernel(tsg_model m, EngineDev D, int superstep) {
   const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -126,20 +127,12 @@ __global__ __launch_bounds__(256) void score_frontier_kernel(tsg_model m, Engine
   if (it[IT_SLOT] < 0) return;                               // this search emitted nothing (finished batch)
   const int ncand = it[IT_NCAND];
   const int b = it[IT_SLOT], e = it[IT_EXP];
-  constexpr int LV = TSG_UP_LEVELS;  // levels 0..5 resolve a lane's ancestor inside a 64-chunk, level 6 hops chunks
-  int32_t* up = D.e.exp_up + (size_t)b * D.e.exp_cap * LV;
-  // up[e][*]: every lane computes the same chain (wave-uniform addresses), lane 0 stores.  The first 7
-  // levels stay in registers: this wave must not read back what it has just stored.
-  int mine[7];
-  {
-    int a = it[IT_PARENT];
-#pragma unroll
-    for (int k = 0; k < 7; ++k) {
-      mine[k] = a;
-      if (lane == 0) up[(size_t)e * LV + k] = a;
-      a = (a >= 0) ? up[(size_t)a * LV + k] : -1;
-    }
-  }
+  constexpr int LV = TSG_UP_LEVELS;  // = 64 ancestors per slot
+  int32_t* anc = D.e.exp_up + (size_t)b * D.e.exp_cap * LV;
+  const int parent = it[IT_PARENT];
+  // lane i: the (i+1)-th ancestor of e; kept in a register (this wave must not read back its own store)
+  int mine = lane == 0 ? parent : (parent >= 0 ? anc[(size_t)parent * LV + lane - 1] : -1);
+  anc[(size_t)e * LV + lane] = mine;
   if (ncand < 2) return;  // warm-up rows and single-successor expansions need no model call (search.py:302)
   const int rid = it[IT_RID], des = it[IT_DES];
   const float lp_parent = __int_as_float(it[IT_LP]);
@@ -151,16 +144,13 @@ __global__ __launch_bounds__(256) void score_frontier_kernel(tsg_model m, Engine
   load_row<JT>(htop + (size_t)e * hp, q, J, lane);
   AttnAcc<JT> acc;
   attn_init(acc);
-  int anchor = e;  // the (64 * chunk)-th ancestor
+  int anchor = e;   // the (64 * chunk)-th ancestor
+  int list = mine;  // lane i: the (i+1)-th ancestor of `anchor`
   for (int base = 0; base < depth; base += 64) {
     const int n = depth - base < 64 ? depth - base : 64;
-    // lane t: the t-th ancestor of `anchor` (distance t = lane), -1 beyond the chain
-    int cur = lane < n ? anchor : -1;
-#pragma unroll
-    for (int k = 0; k < 6; ++k) {
-      const bool hop = ((lane >> k) & 1) && cur >= 0;
-      if (hop) cur = (cur == e) ? mine[k] : up[(size_t)cur * LV + k];
-    }
+    // lane t: the ancestor at distance t of `anchor` (lane 0 = the anchor itself)
+    const int up1 = __shfl_up(list, 1, TSG_WAVE);
+    const int cur = lane == 0 ? anchor : up1;
     // groups of 4 rows, software-pipelined: group g+1 is loading while group g is folded
     float keyA[4][JT], keyB[4][JT];
     unsigned presA = 0, presB = 0;
@@ -190,7 +180,10 @@ __global__ __launch_bounds__(256) void score_frontier_kernel(tsg_model m, Engine
 #endif
       }
     }
-    if (base + 64 < depth) anchor = (anchor == e) ? mine[6] : up[(size_t)anchor * LV + 6];
+    if (base + 64 < depth) {  // next chunk: hop 64 up, fetch that slot's list
+      anchor = __shfl(list, 63, TSG_WAVE);
+      list = anc[(size_t)anchor * LV + lane];
+    }
   }
   float pooled[JT];
   const float inv = 1.0f / acc.l;

@@ -321,7 +321,7 @@ class AStarEngine(object):
         self.table = torch.zeros((B, n), dtype=i32, device=dev)
         self.nodes = torch.empty((B, self.node_cap, 8), dtype=i32, device=dev)
         self.exp_meta = torch.empty((B, self.exp_cap, 4), dtype=i32, device=dev)
-        self.up_levels = 8      # TSG_UP_LEVELS
+        self.up_levels = 64     # TSG_UP_LEVELS: ancestors listed per expanded node
         w1 = float(tables.hparams[41])
         self.prune_spread = (abs(1.0 - w1) + abs(w1)) * (1.0 + 1e-6) if prune else 0.0
         self.exp_up = torch.empty((B, self.exp_cap, self.up_levels), dtype=i32, device=dev)
@@ -350,6 +350,7 @@ class AStarEngine(object):
             e.shared_counters = self.counters[streams].data_ptr()
             self.c_engines.append(e)
         self.side_streams = [torch.cuda.Stream(device=dev) for _ in range(streams)] if streams > 1 else None
+        self._pinned = [torch.zeros((streams + 1, 16), dtype=i32).pin_memory() for _ in range(2)]
         self.last_stats = {}
 
     @staticmethod
@@ -358,7 +359,7 @@ class AStarEngine(object):
         node_cap = min(graph.num_roads, 1 + max_step * graph.max_degree) + 1
         heap_cap = 1 + max_step * graph.max_degree
         return (2 * tables.n_layers * exp_cap * tables.hp * 4 + heap_cap * 8 + graph.num_roads * 4
-                + node_cap * 32 + exp_cap * (16 + 4 * 8) + 40 * 4 + 32 + graph.max_degree * 4)
+                + node_cap * 32 + exp_cap * (16 + 4 * 64) + 40 * 4 + 32 + graph.max_degree * 4)
 
     @torch.no_grad()
     def run(self, prefix_ptr, prefix_rid, prefix_time, des, default_len, max_step, allow_label=None,
@@ -429,7 +430,9 @@ class AStarEngine(object):
         prof_n = (C.c_int32 * nk)()
         prof_items = 0
         chunk_i = 0
-        inflight = [[] for _ in range(K)]       # events of the chunks enqueued per stream (<= 2 kept in flight)
+        inflight = [[] for _ in range(K)]
+        pending = []
+        cnt = torch.zeros((K + 1, 16), dtype=torch.int32)
         with torch.cuda.device(dev):
             self.counters.zero_()
             for k in range(K):
@@ -449,21 +452,32 @@ class AStarEngine(object):
                                                              C.byref(self.c_engines[k]), supersteps, chunk, handles[k],
                                                              prof_ms, prof_n), 'tsg_engine_run_profiled')
                     cnt = self.counters.cpu()
+                    pending = []
                     prof_items += int(self.slot_state[:, 32].sum()) - items0
                 else:
+                    # two chunks stay in flight: the completion counter of chunk i-1 is inspected (from a pinned
+                    # snapshot copied on the stream) only after chunk i has been enqueued, so the GPU never waits
+                    # for the host round trip
                     for k in range(K):
-                        if len(inflight[k]) >= 2:
-                            inflight[k].pop(0).synchronize()
                         _lib.check(L.tsg_engine_run(C.byref(m), C.byref(g), C.byref(od), C.byref(self.c_engines[k]),
                                                     supersteps, chunk, handles[k]), 'tsg_engine_run')
-                        ev = torch.cuda.Event()
-                        ev.record(streams[k])
-                        inflight[k].append(ev)
-                    if K == 1:
-                        cnt = self.counters.cpu()
-                    else:
-                        inflight[0][0].synchronize()      # oldest chunk of stream 0: bounds the host run-ahead
-                        cnt = self.counters.cpu()         # racy read of monotonic counters: only ever behind
+                    snap = self._pinned[chunk_i % 2]
+                    with torch.cuda.stream(streams[0]):
+                        snap.copy_(self.counters, non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record(streams[0])
+                    pending.append((ev, snap))
+                    if K > 1:
+                        for k in range(1, K):       # bound the run-ahead on the other streams too
+                            evk = torch.cuda.Event()
+                            evk.record(streams[k])
+                            inflight[k].append(evk)
+                            if len(inflight[k]) > 2:
+                                inflight[k].pop(0).synchronize()
+                    if len(pending) >= 2:
+                        ev0, snap0 = pending.pop(0)
+                        ev0.synchronize()
+                        cnt = snap0.clone()
                 supersteps += chunk
                 chunk_i += 1
                 if int(cnt[K, 3]) >= n_od:
