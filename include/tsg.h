@@ -250,6 +250,14 @@ int tsg_engine_reset(const tsg_engine* e, const tsg_graph* g, void* stream);
 int tsg_engine_run(const tsg_model* m, const tsg_graph* g, const tsg_od_batch* od, const tsg_engine* e,
                    int32_t first_superstep, int32_t n_supersteps, void* stream);
 
+/* HIP-graph form of tsg_engine_run (no counterpart in the reference): capture the launches of `n_supersteps`
+ * supersteps once from `stream` (not the legacy default stream), replay them with one graph launch per
+ * chunk.  The graph holds the pointer values of m / g / od / e at capture time: create one per OD batch. */
+int tsg_engine_graph_create(const tsg_model* m, const tsg_graph* g, const tsg_od_batch* od, const tsg_engine* e,
+                            int32_t n_supersteps, void* stream, void** exec_out);
+int tsg_engine_graph_launch(void* exec, void* stream);
+int tsg_engine_graph_destroy(void* exec);
+
 /* Measurement variant of tsg_engine_run: identical launches, each bracketed by HIP events on `stream`.
  * SYNCHRONISES the stream before returning.  Adds per-kernel elapsed ms and launch counts to
  * ms_sum_host / launches_host, both HOST arrays of 2 + TSG_MAX_LAYERS entries:

@@ -15,7 +15,8 @@ TSG_H_HIDDEN = 10
 STATUS_UNTOUCHED, STATUS_REACHED, STATUS_FALLBACK, STATUS_OVERFLOW = 0, 1, 2, 0x100
 
 EXPORTS = ('tsg_version', 'tsg_gemm_f32', 'tsg_gat_forward', 'tsg_gat_build_input', 'tsg_lstm_step_batched',
-           'tsg_score_candidates', 'tsg_engine_reset', 'tsg_engine_run', 'tsg_engine_run_profiled', 'tsg_frontier_expand_select',
+           'tsg_score_candidates', 'tsg_engine_reset', 'tsg_engine_run', 'tsg_engine_run_profiled', 'tsg_engine_graph_create', 'tsg_engine_graph_launch',
+           'tsg_engine_graph_destroy', 'tsg_frontier_expand_select',
            'tsg_score_frontier')
 
 _p = C.c_void_p
@@ -97,6 +98,10 @@ def lib():
                                  _i32, _i32, _p]
     L.tsg_engine_run_profiled.argtypes = [C.POINTER(Model), C.POINTER(Graph), C.POINTER(OdBatch), C.POINTER(Engine),
                                           _i32, _i32, _p, C.POINTER(C.c_float), C.POINTER(_i32)]
+    L.tsg_engine_graph_create.argtypes = [C.POINTER(Model), C.POINTER(Graph), C.POINTER(OdBatch), C.POINTER(Engine),
+                                          _i32, _p, C.POINTER(_p)]
+    L.tsg_engine_graph_launch.argtypes = [_p, _p]
+    L.tsg_engine_graph_destroy.argtypes = [_p]
     L.tsg_frontier_expand_select.argtypes = [C.POINTER(Graph), C.POINTER(OdBatch), C.POINTER(Engine), _i32, _p]
     L.tsg_score_frontier.argtypes = [C.POINTER(Model), C.POINTER(Graph), C.POINTER(Engine), _i32, _p]
     for name in EXPORTS:

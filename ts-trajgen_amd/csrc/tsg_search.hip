@@ -880,6 +880,46 @@ extern "C" int tsg_engine_run(const tsg_model* m, const tsg_graph* g, const tsg_
   return 0;
 }
 
+// HIP-graph form of tsg_engine_run: the launches of `n_supersteps` supersteps are captured once from
+// `stream` (which must not be the legacy default stream) and replayed with one graph launch per chunk,
+// which removes most of the per-kernel launch gaps (five short kernels per superstep).
+extern "C" int tsg_engine_graph_create(const tsg_model* m, const tsg_graph* g, const tsg_od_batch* od,
+                                       const tsg_engine* e, int32_t n_supersteps, void* stream, void** exec_out) {
+  if (!exec_out || n_supersteps <= 0) return TSG_E_INVALID;
+  *exec_out = nullptr;
+  int rc = check_engine(m, g, od, e);
+  if (rc) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  if (s == nullptr) return TSG_E_INVALID;
+  TSG_HIP_TRY(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+  rc = tsg_engine_run(m, g, od, e, 0, n_supersteps, stream);
+  hipGraph_t graph = nullptr;
+  hipError_t he = hipStreamEndCapture(s, &graph);
+  if (rc) {
+    if (graph) (void)hipGraphDestroy(graph);
+    return rc;
+  }
+  if (he != hipSuccess || !graph) return -(int)he - 1000;
+  hipGraphExec_t exec = nullptr;
+  he = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(graph);
+  if (he != hipSuccess) return -(int)he - 1000;
+  *exec_out = (void*)exec;
+  return 0;
+}
+
+extern "C" int tsg_engine_graph_launch(void* exec, void* stream) {
+  if (!exec) return TSG_E_INVALID;
+  TSG_HIP_TRY(hipGraphLaunch((hipGraphExec_t)exec, (hipStream_t)stream));
+  return 0;
+}
+
+extern "C" int tsg_engine_graph_destroy(void* exec) {
+  if (!exec) return 0;
+  TSG_HIP_TRY(hipGraphExecDestroy((hipGraphExec_t)exec));
+  return 0;
+}
+
 // Profiling variant: same launches, each bracketed by HIP events on `stream`; synchronises the stream
 // before returning (the caller polls the completion counter after every chunk anyway).
 extern "C" int tsg_engine_run_profiled(const tsg_model* m, const tsg_graph* g, const tsg_od_batch* od,

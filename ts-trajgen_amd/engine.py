@@ -300,7 +300,7 @@ class AStarEngine(object):
     while one sub-engine is in its latency-bound frontier / scoring kernels, another keeps the matrix cores
     busy with its LSTM step.  Workspaces are disjoint slices of the same tensors."""
 
-    def __init__(self, tables, graph, slots, max_step, max_prefix=1, lmax=256, streams=1, prune=True):
+    def __init__(self, tables, graph, slots, max_step, max_prefix=1, lmax=256, streams=1, prune=True, use_graph=True):
         self.tables, self.graph = tables, graph
         dev = self.device = tables.device
         n = graph.num_roads
@@ -349,7 +349,8 @@ class AStarEngine(object):
             e.counters_bytes = 64
             e.shared_counters = self.counters[streams].data_ptr()
             self.c_engines.append(e)
-        self.side_streams = [torch.cuda.Stream(device=dev) for _ in range(streams)] if streams > 1 else None
+        self.side_streams = [torch.cuda.Stream(device=dev) for _ in range(streams)]
+        self.use_graph = bool(use_graph)
         self._pinned = [torch.zeros((streams + 1, 16), dtype=i32).pin_memory() for _ in range(2)]
         self.last_stats = {}
 
@@ -422,7 +423,7 @@ class AStarEngine(object):
         m, g = self.tables.c_model, self.graph.c_graph
         K = self.n_sub
         main = torch.cuda.current_stream(dev)
-        streams = self.side_streams if K > 1 else [main]
+        streams = self.side_streams
         handles = [C.c_void_p(s.cuda_stream) for s in streams]
         supersteps = 0
         nk = 2 + _lib.TSG_MAX_LAYERS
@@ -432,12 +433,12 @@ class AStarEngine(object):
         chunk_i = 0
         inflight = [[] for _ in range(K)]
         pending = []
+        graphs = [None] * K
         cnt = torch.zeros((K + 1, 16), dtype=torch.int32)
         with torch.cuda.device(dev):
             self.counters.zero_()
             for k in range(K):
-                if K > 1:
-                    streams[k].wait_stream(main)
+                streams[k].wait_stream(main)
                 _lib.check(L.tsg_engine_reset(C.byref(self.c_engines[k]), C.byref(g), handles[k]), 'tsg_engine_reset')
             # every superstep each unfinished slot advances by >= 1 expansion / prefix element / finished OD
             bound = (math.ceil(n_od / self.slots) + 1) * (self.max_step + self.max_prefix + 2) + 8
@@ -459,8 +460,18 @@ class AStarEngine(object):
                     # snapshot copied on the stream) only after chunk i has been enqueued, so the GPU never waits
                     # for the host round trip
                     for k in range(K):
-                        _lib.check(L.tsg_engine_run(C.byref(m), C.byref(g), C.byref(od), C.byref(self.c_engines[k]),
-                                                    supersteps, chunk, handles[k]), 'tsg_engine_run')
+                        if self.use_graph and graphs[k] is None:
+                            gx = C.c_void_p()
+                            _lib.check(L.tsg_engine_graph_create(C.byref(m), C.byref(g), C.byref(od),
+                                                                 C.byref(self.c_engines[k]), chunk, handles[k],
+                                                                 C.byref(gx)), 'tsg_engine_graph_create')
+                            graphs[k] = gx
+                        if self.use_graph:
+                            _lib.check(L.tsg_engine_graph_launch(graphs[k], handles[k]), 'tsg_engine_graph_launch')
+                        else:
+                            _lib.check(L.tsg_engine_run(C.byref(m), C.byref(g), C.byref(od),
+                                                        C.byref(self.c_engines[k]), supersteps, chunk, handles[k]),
+                                       'tsg_engine_run')
                     snap = self._pinned[chunk_i % 2]
                     with torch.cuda.stream(streams[0]):
                         snap.copy_(self.counters, non_blocking=True)
@@ -487,9 +498,11 @@ class AStarEngine(object):
                                        % (bound, int(cnt[K, 3]), n_od))
             for s in streams:
                 s.synchronize()
-            if K > 1:
-                for s in streams:
-                    main.wait_stream(s)
+            for s in streams:
+                main.wait_stream(s)
+            for gx in graphs:
+                if gx is not None:
+                    L.tsg_engine_graph_destroy(gx)
             cnt = self.counters.cpu()
         if int(cnt[K, 6]) != 0:
             raise RuntimeError('A* engine hit a workspace cap (node/heap/exp capacity)')
