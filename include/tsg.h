@@ -272,6 +272,43 @@ int tsg_frontier_expand_select(const tsg_graph* g, const tsg_od_batch* od, const
 int tsg_score_frontier(const tsg_model* m, const tsg_graph* g, const tsg_engine* e, int32_t superstep,
                        void* stream);
 
+/* ---- stochastic rollouts --------------------------------------------------------------------------------
+ * Replaces the per-trajectory loops of Searcher.road_random_sample (search.py:614-716) and, with a region
+ * graph (tsg_graph.dist_table set), DoubleLayerSearcher.region_random_sample (search.py:1163-1256): every
+ * row is one (prefix, destination, default_len) rollout; one step appends at most one point per row.
+ * The reference's `multinomial(1)` (search.py:686,1233) is an inverse-CDF draw here: the k-th model
+ * evaluation of row b takes uniform[b][k] and picks the first candidate i with u < f_0 + ... + f_i
+ * (fp32, candidate order), else the last.  All arrays are device memory owned by the caller. */
+typedef struct tsg_rollout {
+  int32_t n_traj, lmax;       /* rows; row width of out_rid / out_time and state rows per trajectory */
+  int32_t n_draws, reserved;  /* columns of `uniform` (>= max(20, default_len) covers every row) */
+  int32_t* out_rid;           /* [n_traj][lmax] prefix pre-filled; grows in place */
+  int32_t* out_time;          /* [n_traj][lmax] time codes, prefix pre-filled */
+  int32_t* len;               /* [n_traj] in: prefix length >= 1; out: returned length (after the
+                                 trace[:default_len] cut of search.py:716 when des was not reached) */
+  int32_t* n_state;           /* [n_traj] zero at start: tokens already run through the LSTM */
+  int32_t* n_drawn;           /* [n_traj] zero at start: uniforms consumed */
+  int32_t* status;            /* [n_traj] zero at start: 0 running, TSG_STATUS_REACHED, TSG_STATUS_FALLBACK
+                                 (budget max(20, default_len) spent or dead end), | TSG_STATUS_OVERFLOW when lmax or
+                                 n_draws ran out */
+  const int32_t* des;         /* [n_traj] */
+  const int32_t* default_len; /* [n_traj] */
+  const int32_t* start_code;  /* [n_traj] time code of the last prefix point (search.py:632) */
+  const float* uniform;       /* [n_traj][n_draws] in [0, 1) */
+  float* prob_log;            /* optional [n_traj][n_draws][max_degree]: the probability vector of every draw */
+  float* h[TSG_MAX_LAYERS];   /* [n_traj * lmax][hp] per layer; row b * lmax + i = state after point i of row b */
+  float* c[TSG_MAX_LAYERS];
+  size_t state_bytes;         /* bytes of each h[l] / c[l] */
+  int64_t* prev_idx;          /* [n_traj] work rows of the LSTM step */
+  int64_t* out_idx;           /* [n_traj] */
+  int32_t* rid;               /* [n_traj] */
+  int32_t* tcode;             /* [n_traj] */
+} tsg_rollout;
+
+/* Enqueue `n_steps` rollout steps.  A row with a P-point prefix needs P - 1 warm-up steps, then one step per
+ * appended point, then one to notice that it is finished: P + max(20, default_len) steps finish every row. */
+int tsg_rollout_run(const tsg_model* m, const tsg_graph* g, const tsg_rollout* r, int32_t n_steps, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,8 +1,8 @@
 """CPU restatement of the A* searches of search.py.  TEST INFRASTRUCTURE (see oracle/__init__.py).
 
 Follows search.py:14-52 (SearchNode), :240-424 (Searcher.astar_search), :426-612
-(astar_search_in_region), :859-934 (DoubleLayerSearcher.astar_search) and :936-1117
-(region-level A*).  ``queue.PriorityQueue`` is a locked ``heapq`` of ``(priority,
+(astar_search_in_region), :859-934 (DoubleLayerSearcher.astar_search), :936-1117
+(region-level A*), :614-716 (road_random_sample) and :1163-1256 (region_random_sample).  ``queue.PriorityQueue`` is a locked ``heapq`` of ``(priority,
 SearchNode)`` tuples; the oracle uses ``heapq`` directly with the same tuple shape so
 that exact-priority ties fall to ``SearchNode.__lt__`` on the node's *current*
 log_prob and then to heap position, as in the reference.
@@ -264,3 +264,114 @@ def double_layer_astar_search(region_model, road_model, tables, start_rid, start
     if trace_loc[-1] != des and fail_log is not None:
         fail_log.add((trace_loc[-1], des))
     return trace_loc, trace_tim, is_astar
+
+
+# ---------------------------------------------------------------------------------------------------
+# stochastic rollouts (search.py:614-716 and :1163-1256)
+def multinomial_choice(prob):
+    """search.py:686 / :1233: `prob.multinomial(1).item()` on torch's global CPU generator."""
+    return int(prob.multinomial(1).item())
+
+
+def inverse_cdf_choice(prob, u):
+    """The draw rule of the device path (include/tsg.h, tsg_rollout): first i with u < p_0 + ... + p_i,
+    accumulated in fp32 in candidate order; the last candidate when no prefix sum exceeds u."""
+    cum = np.float32(0.0)
+    for i, p in enumerate(np.asarray(prob, dtype=np.float32)):
+        cum = np.float32(cum + p)
+        if np.float32(u) < cum:
+            return i
+    return len(prob) - 1
+
+
+def road_random_sample(model, adjacent_list, road_center_gps, road_length, rtd, trace_loc, trace_tim, des,
+                       default_len, choose=None, dist_fn=None, log=None):
+    """search.py:614-716.  ``choose(prob, k)`` picks the index of the k-th model evaluation (default: torch
+    multinomial like the reference).  ``log`` collects (prob list, chosen index) per evaluation."""
+    if choose is None:
+        choose = lambda p, k: multinomial_choice(p)
+    if dist_fn is None:
+        dist_fn = geodesic.candidate_dis
+    trace_loc = list(trace_loc)
+    trace_tim = list(trace_tim)
+    start_time = trace_tim[-1]
+    weekday_off = 1440 if start_time >= 1440 else 0                      # :631-634
+    step = len(trace_loc) - 1                                            # :635
+    max_step = max(20, default_len)                                      # :636
+    now_road = trace_loc[-1]
+    now_date_time = (start_time - weekday_off) * 60                      # :638 (never advanced afterwards)
+    des_gps = road_center_gps[str(des)]
+    k = 0
+    while now_road != des and step < max_step:                           # :640
+        if str(now_road) not in adjacent_list:
+            break                                                        # :708-710
+        cand = adjacent_list[str(now_road)]
+        if len(cand) == 0:
+            break                                                        # :646-648
+        if len(cand) == 1:
+            next_road = cand[0]                                          # :650-665
+        else:
+            dis = [dist_fn(des_gps, road_center_gps[str(c)]) for c in cand]          # :667-672
+            prob = model.predict(trace_loc, trace_tim, des, cand, dis)               # :680-683
+            idx = choose(prob, k)                                                    # :686
+            if log is not None:
+                log.append(([float(x) for x in prob], int(idx)))
+            k += 1
+            next_road = cand[idx]
+        cost = travel_cost(rtd, road_length, now_date_time // 3600, now_road)        # :656-660 / :698-702
+        next_time = (now_date_time + cost) % 86400
+        trace_tim.append(next_time // 60 + weekday_off)
+        trace_loc.append(next_road)
+        now_road = next_road
+        step += 1                                                        # :711
+    if trace_loc[-1] == des:
+        return trace_loc, trace_tim                                      # :712-713
+    return trace_loc[:default_len], trace_tim[:default_len]              # :714-716
+
+
+def region_random_sample(region_model, region_adjacent_list, region_dist, region_time_distribution, trace_loc,
+                         trace_tim, des, default_len, choose=None, log=None):
+    """search.py:1163-1256."""
+    if choose is None:
+        choose = lambda p, k: multinomial_choice(p)
+    trace_loc = list(trace_loc)
+    trace_tim = list(trace_tim)
+    start_time = trace_tim[-1]
+    weekday_off = 1440 if start_time >= 1440 else 0
+    step = len(trace_loc) - 1
+    max_step = max(20, default_len)
+    now_region = trace_loc[-1]
+    now_date_time = (start_time - weekday_off) * 60                      # :1188 (never advanced afterwards)
+    rtd = region_time_distribution
+    k = 0
+    while now_region != des and step < max_step:                         # :1189
+        if str(now_region) not in region_adjacent_list:
+            break                                                        # :1248-1250
+        cand = [int(c) for c in region_adjacent_list[str(now_region)].keys()]        # :1194-1195
+        if len(cand) == 0:
+            break
+        hour = now_date_time // 3600
+        if len(cand) == 1:
+            next_region = cand[0]
+            who = next_region                                            # :1207 indexes the NEXT region
+        else:
+            dis = [region_dist[c][des] / 100 for c in cand]              # :1218-1220
+            prob = region_model.predict(trace_loc, trace_tim, des, cand, dis)
+            idx = choose(prob, k)                                        # :1233
+            if log is not None:
+                log.append(([float(x) for x in prob], int(idx)))
+            k += 1
+            next_region = cand[idx]
+            who = now_region                                             # :1238 indexes the CURRENT region
+        if rtd[hour][who] != 1:
+            cost = int(rtd[hour][who])
+        else:
+            cost = int(round(region_dist[now_region][next_region] / DEFAULT_SPEED))  # :1210-1211 / :1241-1242
+        next_time = (now_date_time + cost) % 86400
+        trace_tim.append(next_time // 60 + weekday_off)
+        trace_loc.append(next_region)
+        now_region = next_region
+        step += 1
+    if trace_loc[-1] == des:
+        return trace_loc, trace_tim
+    return trace_loc[:default_len], trace_tim[:default_len]

@@ -193,3 +193,83 @@ def test_g7_double_layer(road, road_model, region):
     l1, t1, f1 = s.astar_search(region_model, road_model, c['start'], c['start_time'], c['des'], c['default_len'],
                                 max_step=c['max_step'])
     assert l1 == c['loc'] and t1 == c['tim'] and f1 == c['is_astar']
+
+
+def _midpoint_uniforms(cases, n_draws):
+    """Uniforms that make the inverse-CDF rule reproduce the golden draws: the midpoint of the drawn
+    candidate's CDF interval (golden probabilities, fp32 running sum)."""
+    u = np.zeros((len(cases), n_draws), dtype=np.float32)
+    for b, c in enumerate(cases):
+        for k, (p, idx) in enumerate(c['draws']):
+            cum = np.cumsum(np.asarray(p, dtype=np.float32), dtype=np.float32)
+            lo = 0.0 if idx == 0 else float(cum[idx - 1])
+            u[b, k] = 0.5 * (lo + float(cum[idx]))
+    return u
+
+
+def test_g8_random_sample(road, road_model, region):
+    """Rollouts (search.py:614-716, :1163-1256) against the reference goldens: same draws -> same
+    trajectories, and the probability vector of every draw within 1e-4 relative."""
+    from ts_trajgen_amd.search import DoubleLayerSearcher
+    g8 = load_json('g8_random_sample.json')
+    t = region.tables(road)
+    s = DoubleLayerSearcher(DEV, t['adjacent_list'], t['road_center_gps'], t['road_length'],
+                            t['region_adjacent_list'], t['region_dist'], t['region_transfer_freq'],
+                            t['rid2region'], t['region2rid'], road.rtd, region.npz['region_time_distribution'])
+    cases = g8['road']
+    nd = max(20, max(c['default_len'] for c in cases))
+    res = s.road_search.random_sample_batch(road_model, [(c['prefix_loc'], c['prefix_tim']) for c in cases],
+                                            [c['des'] for c in cases], [c['default_len'] for c in cases],
+                                            uniforms=_midpoint_uniforms(cases, nd), return_probs=True)
+    probs = res['probs'].cpu().numpy()
+    for b, c in enumerate(cases):
+        assert res['loc'][b] == c['loc'] and res['tim'][b] == c['tim'], b
+        assert int(res['n_drawn'][b]) == len(c['draws'])
+        for k, (p, _) in enumerate(c['draws']):
+            np.testing.assert_allclose(probs[b, k, :len(p)], p, rtol=1e-4, atol=1e-7)
+    region_model = build_generator(region, DEV)
+    cases = g8['region']
+    res = s.region_random_sample_batch(region_model, [(c['prefix_loc'], c['prefix_tim']) for c in cases],
+                                       [c['des'] for c in cases], [c['default_len'] for c in cases],
+                                       uniforms=_midpoint_uniforms(cases, 20))
+    for b, c in enumerate(cases):
+        assert res['loc'][b] == c['loc'] and res['tim'][b] == c['tim'], b
+    # reference one-row signatures (torch.rand draws: only the shape of the result is checked)
+    c = g8['road'][1]
+    loc, tim = s.road_random_sample(road_model, c['prefix_loc'], c['prefix_tim'], c['des'], c['default_len'])
+    assert loc[:len(c['prefix_loc'])] == c['prefix_loc'][:len(loc)] and len(loc) == len(tim)
+    c = g8['region'][0]
+    loc, tim = s.region_random_sample(region_model, c['prefix_loc'], c['prefix_tim'], c['des'], c['default_len'])
+    assert len(loc) == len(tim) and len(loc) >= 1
+
+
+def test_random_sample_vs_oracle(road, road_model):
+    """512 rollouts with random uniforms against the oracle using the same inverse-CDF rule; a row may differ
+    only where a uniform falls within 1e-5 of a CDF boundary."""
+    from oracle import search as osr
+    from ts_trajgen_amd.search import Searcher
+    s = Searcher(DEV, road.adjacent_list, road.rid_gps, road.road_length, road.rtd)
+    rng = np.random.RandomState(3)
+    n = 512
+    keys = [int(k) for k in road.adjacent_list.keys()]
+    start = [keys[i] for i in rng.randint(len(keys), size=n)]
+    des = rng.randint(road.n, size=n)
+    code = rng.randint(0, 2880, size=n)
+    dl = rng.randint(1, 35, size=n)
+    u = rng.rand(n, 40).astype(np.float32)
+    res = s.random_sample_batch(road_model, [([start[i]], [int(code[i])]) for i in range(n)], des, dl, uniforms=u)
+    m = road.oracle_model()
+    rtd = road.rtd.astype(int)
+    bad = 0
+    for i in range(0, n, 4):          # every 4th row through the (slow) oracle
+        log = []
+        loc, tim = osr.road_random_sample(m, road.adjacent_list, road.rid_gps, road.road_length, rtd, [start[i]],
+                                          [int(code[i])], int(des[i]), int(dl[i]),
+                                          choose=lambda p, k, i=i: osr.inverse_cdf_choice(p.numpy(), u[i, k]),
+                                          log=log)
+        if [int(x) for x in loc] != res['loc'][i] or [int(x) for x in tim] != res['tim'][i]:
+            near = any(np.min(np.abs(np.cumsum(np.float32(p), dtype=np.float32) - u[i, k])) < 1e-5
+                       for k, (p, _) in enumerate(log))
+            assert near, i
+            bad += 1
+    assert bad <= 2

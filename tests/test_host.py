@@ -46,6 +46,7 @@ def test_struct_sizes_match_header():
     assert ctypes.sizeof(_lib.Graph) == 8 + 8 * 8
     assert ctypes.sizeof(_lib.Model) == 16 + (3 + 8 + 5) * 8
     assert ctypes.sizeof(_lib.Engine) == 16 + 5 * 16 + 16 + 8 + 8 * 8 + 8 + 3 * 16 + 8
+    assert ctypes.sizeof(_lib.Rollout) == 16 + 11 * 8 + 8 * 8 + 8 + 4 * 8
 
 
 def test_gate_permutation_roundtrip():

@@ -102,3 +102,40 @@ def test_g7_double_layer(road, region):
         assert loc == c['loc'] and tim == c['tim'] and is_astar == c['is_astar']
     assert sorted([list(map(int, x)) for x in fail]) == region.meta['fail_find_log']
     assert sorted([list(map(int, x)) for x in rfail]) == region.meta['region_fail_find_log']
+
+
+def test_g8_random_sample(road, region):
+    """road_random_sample / region_random_sample (search.py:614-716, :1163-1256): with torch's generator seeded
+    like the reference run the oracle draws the same stream and must return the same trajectories; the
+    probability vector of every draw is compared too."""
+    g8 = load_json('g8_random_sample.json')
+    m = road.oracle_model()
+    rtd = road.rtd.astype(int)
+    for c in g8['road']:
+        log = []
+        torch.manual_seed(c['seed'])
+        loc, tim = osr.road_random_sample(m, road.adjacent_list, road.rid_gps, road.road_length, rtd,
+                                          c['prefix_loc'], c['prefix_tim'], c['des'], c['default_len'], log=log)
+        assert [int(x) for x in loc] == c['loc'] and [int(x) for x in tim] == c['tim']
+        assert len(log) == len(c['draws'])
+        for (p, i), (rp, ri) in zip(log, c['draws']):
+            assert i == ri
+            np.testing.assert_allclose(p, rp, rtol=1e-4, atol=1e-7)
+    rm = region.oracle_model()
+    t = region.tables(road)
+    for c in g8['region']:
+        log = []
+        torch.manual_seed(c['seed'])
+        loc, tim = osr.region_random_sample(rm, t['region_adjacent_list'], t['region_dist'],
+                                            t['region_time_distribution'], c['prefix_loc'], c['prefix_tim'],
+                                            c['des'], c['default_len'], log=log)
+        assert [int(x) for x in loc] == c['loc'] and [int(x) for x in tim] == c['tim']
+        assert [i for _, i in log] == [ri for _, ri in c['draws']]
+
+
+def test_inverse_cdf_choice():
+    p = np.array([0.25, 0.5, 0.25], dtype=np.float32)
+    assert osr.inverse_cdf_choice(p, 0.0) == 0 and osr.inverse_cdf_choice(p, 0.2499) == 0
+    assert osr.inverse_cdf_choice(p, 0.25) == 1 and osr.inverse_cdf_choice(p, 0.7499) == 1
+    assert osr.inverse_cdf_choice(p, 0.75) == 2 and osr.inverse_cdf_choice(p, 0.99999) == 2
+    assert osr.inverse_cdf_choice(np.array([0.3, 0.3], dtype=np.float32), 0.9) == 1   # sums short of u: last

@@ -276,10 +276,11 @@ def gen_search_goldens(net, model):
 
 
 # ----------------------------------------------------------------------------- G7: two-stage
-def gen_double_layer(net, model, rt):
+def build_region_model(net, model, rt):
     nreg = rt['num_regions']
     n = net.num_roads
     with torch.no_grad():
+        model.function_h._setup_node_emb()
         node_emb = model.function_h.node_emb_feature
         mat = np.zeros((nreg, n))
         for rid, reg in rt['rid2region'].items():
@@ -293,6 +294,13 @@ def gen_double_layer(net, model, rt):
         region_model.function_h.gat_encoder.bias.normal_(0, 0.1)
         region_model.function_g.out_fc.weight.mul_(8.0)
     region_model.train(False)
+    return region_model, region_feature
+
+
+def gen_double_layer(net, model, rt):
+    nreg = rt['num_regions']
+    n = net.num_roads
+    region_model, region_feature = build_region_model(net, model, rt)
     ref_search.PriorityQueue = queue.PriorityQueue
     searcher = ref_search.DoubleLayerSearcher('cpu', net.adjacent_list, net.rid_gps, net.road_length,
                                               rt['region_adjacent_list'], rt['region_dist'],
@@ -337,10 +345,91 @@ def gen_double_layer(net, model, rt):
     print('G7 done', sum(c['loc'][-1] == c['des'] for c in cases), 'reached of', len(cases))
 
 
+# ----------------------------------------------------------------------------- G8: stochastic rollouts
+class _RecordingMultinomial(object):
+    """Wraps torch.Tensor.multinomial while a rollout runs: records (probabilities, drawn index)."""
+    log = None
+    orig = torch.Tensor.multinomial
+
+    @staticmethod
+    def patched(self, *a, **kw):
+        out = _RecordingMultinomial.orig(self, *a, **kw)
+        if _RecordingMultinomial.log is not None:
+            _RecordingMultinomial.log.append(([float(x) for x in self.detach().tolist()], int(out.item())))
+        return out
+
+
+def gen_random_sample(net, model, rt):
+    """road_random_sample (search.py:614-716) and region_random_sample (:1163-1256) under
+    torch.manual_seed(1000 + i); stored: inputs, outputs and every (probability vector, drawn index)."""
+    region_model, _ = build_region_model(net, model, rt)
+    ref = dict(np.load(os.path.join(OUT, 'region_model.npz')))
+    for k, v in sd_np(region_model.function_g).items():
+        assert np.array_equal(ref['g.' + k], v), k            # same region model as G7
+    ref_search.PriorityQueue = queue.PriorityQueue
+    searcher = ref_search.DoubleLayerSearcher('cpu', net.adjacent_list, net.rid_gps, net.road_length,
+                                              rt['region_adjacent_list'], rt['region_dist'],
+                                              rt['region_transfer_freq'], rt['rid2region'], rt['region2rid'],
+                                              net.road_time_distribution, rt['region_time_distribution'])
+    road_searcher = ref_search.Searcher('cpu', net.adjacent_list, net.rid_gps, net.road_length,
+                                        net.road_time_distribution)
+    with open(os.path.join(OUT, 'g5_astar.json')) as f:
+        g5 = json.load(f)['cases']
+    torch.Tensor.multinomial = _RecordingMultinomial.patched
+    rng = np.random.RandomState(21)
+    n = net.num_roads
+    road_cases, region_cases = [], []
+    try:
+        for i in range(40):
+            base = g5[(i * 5) % len(g5)]
+            k = 1 if i % 3 == 0 else min(len(base['loc']), 2 + i % 4)         # prefix length
+            loc, tim = base['loc'][:k], base['tim'][:k]
+            des = base['des'] if i % 5 != 4 else int(rng.randint(n))
+            dl = int(rng.randint(2, 30)) if i % 4 else int(rng.randint(21, 40))
+            _RecordingMultinomial.log = []
+            torch.manual_seed(1000 + i)
+            with torch.no_grad():
+                o_loc, o_tim = road_searcher.road_random_sample(model, loc, tim, des, dl)
+            road_cases.append({'prefix_loc': loc, 'prefix_tim': tim, 'des': int(des), 'default_len': dl,
+                               'seed': 1000 + i, 'loc': [int(x) for x in o_loc], 'tim': [int(x) for x in o_tim],
+                               'draws': _RecordingMultinomial.log})
+        nreg = rt['num_regions']
+        for i in range(16):
+            s0, d0 = int(rng.randint(nreg)), int(rng.randint(nreg))
+            t0 = int(rng.randint(0, 2880))
+            loc, tim = [s0], [t0]
+            if i % 3 == 1 and str(s0) in rt['region_adjacent_list']:
+                nxt = int(list(rt['region_adjacent_list'][str(s0)].keys())[0])
+                loc, tim = [s0, nxt], [t0, min(t0 + 3, 2879) if t0 < 1440 else min(t0 + 3, 2879)]
+            dl = int(rng.randint(2, 8))
+            _RecordingMultinomial.log = []
+            torch.manual_seed(2000 + i)
+            with torch.no_grad():
+                o_loc, o_tim = searcher.region_random_sample(region_model, loc, tim, d0, dl)
+            region_cases.append({'prefix_loc': loc, 'prefix_tim': tim, 'des': d0, 'default_len': dl,
+                                 'seed': 2000 + i, 'loc': [int(x) for x in o_loc], 'tim': [int(x) for x in o_tim],
+                                 'draws': _RecordingMultinomial.log})
+    finally:
+        torch.Tensor.multinomial = _RecordingMultinomial.orig
+        _RecordingMultinomial.log = None
+    with open(os.path.join(OUT, 'g8_random_sample.json'), 'w') as f:
+        json.dump({'road': road_cases, 'region': region_cases}, f)
+    print('G8 done: road reached', sum(c['loc'][-1] == c['des'] for c in road_cases), 'of', len(road_cases),
+          '; region reached', sum(c['loc'][-1] == c['des'] for c in region_cases), 'of', len(region_cases),
+          '; draws', sum(len(c['draws']) for c in road_cases), sum(len(c['draws']) for c in region_cases))
+
+
 if __name__ == '__main__':
-    gen_g1()
-    net, model = gen_model_goldens()
-    rt = gen_search_goldens(net, model)
-    gen_double_layer(net, model, rt)
+    only = sys.argv[1] if len(sys.argv) > 1 else 'all'
+    if only == 'g8':                      # adds G8 next to the existing files (same deterministic world)
+        net = messy_network()
+        model = build_road_model(net)
+        gen_random_sample(net, model, synth.region_tables(net, tiles=2))
+    else:
+        gen_g1()
+        net, model = gen_model_goldens()
+        rt = gen_search_goldens(net, model)
+        gen_double_layer(net, model, rt)
+        gen_random_sample(net, model, rt)
     for fn in sorted(os.listdir(OUT)):
         print(fn, os.path.getsize(os.path.join(OUT, fn)))

@@ -17,7 +17,7 @@ STATUS_UNTOUCHED, STATUS_REACHED, STATUS_FALLBACK, STATUS_OVERFLOW = 0, 1, 2, 0x
 EXPORTS = ('tsg_version', 'tsg_gemm_f32', 'tsg_gat_forward', 'tsg_gat_build_input', 'tsg_lstm_step_batched',
            'tsg_score_candidates', 'tsg_engine_reset', 'tsg_engine_run', 'tsg_engine_run_profiled', 'tsg_engine_graph_create', 'tsg_engine_graph_launch',
            'tsg_engine_graph_destroy', 'tsg_frontier_expand_select',
-           'tsg_score_frontier')
+           'tsg_score_frontier', 'tsg_rollout_run')
 
 _p = C.c_void_p
 _i32 = C.c_int32
@@ -72,6 +72,14 @@ class Engine(C.Structure):
                 ('shared_counters', _p), ('counters', _p), ('counters_bytes', _sz)]
 
 
+class Rollout(C.Structure):
+    _fields_ = [('n_traj', _i32), ('lmax', _i32), ('n_draws', _i32), ('reserved', _i32),
+                ('out_rid', _p), ('out_time', _p), ('len', _p), ('n_state', _p), ('n_drawn', _p), ('status', _p),
+                ('des', _p), ('default_len', _p), ('start_code', _p), ('uniform', _p), ('prob_log', _p),
+                ('h', _p * TSG_MAX_LAYERS), ('c', _p * TSG_MAX_LAYERS), ('state_bytes', _sz),
+                ('prev_idx', _p), ('out_idx', _p), ('rid', _p), ('tcode', _p)]
+
+
 _lib = None
 
 
@@ -104,6 +112,7 @@ def lib():
     L.tsg_engine_graph_destroy.argtypes = [_p]
     L.tsg_frontier_expand_select.argtypes = [C.POINTER(Graph), C.POINTER(OdBatch), C.POINTER(Engine), _i32, _p]
     L.tsg_score_frontier.argtypes = [C.POINTER(Model), C.POINTER(Graph), C.POINTER(Engine), _i32, _p]
+    L.tsg_rollout_run.argtypes = [C.POINTER(Model), C.POINTER(Graph), C.POINTER(Rollout), _i32, _p]
     for name in EXPORTS:
         getattr(L, name).restype = C.c_int
     _lib = L

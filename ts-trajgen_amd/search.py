@@ -138,6 +138,21 @@ class Searcher(object):
         return self._single(gen_model, trace_loc, trace_tim, des, default_len, max_step, allow_label=[1])
 
 
+    # -- stochastic rollouts (search.py:614-716) ---------------------------------------------------
+    def random_sample_batch(self, gen_model, prefixes, des, default_lens, uniforms=None, generator=None,
+                            return_probs=False):
+        """Many road_random_sample rollouts at once (rollout.py:86-92 asks for (seq_len - 2) * rollout_times
+        of them per trajectory).  See rollout.sample_batch for arguments and the draw rule."""
+        from .rollout import sample_batch
+        return sample_batch(gen_model.tables(), self.graph(), prefixes, des, default_lens, uniforms=uniforms,
+                            generator=generator, return_probs=return_probs)
+
+    def road_random_sample(self, gen_model, trace_loc, trace_tim, des, default_len):
+        res = self.random_sample_batch(gen_model, [(list(trace_loc), list(trace_tim))], [int(des)],
+                                       [int(default_len)])
+        return res['loc'][0], res['tim'][0]
+
+
 class DoubleLayerSearcher(object):
     """Two-stage search (reference: search.py:821-934): region-level A* first (search.py:936-1117), then
     road-level A* inside each region of the region path towards a border road drawn from the transfer
@@ -210,6 +225,20 @@ class DoubleLayerSearcher(object):
         tr, fl = self._region_paths(region_model, [start_region], [start_time], [des_region],
                                     np.asarray([max_step], dtype=np.int32))
         return tr[0], fl[0]
+
+    # -- stochastic region rollouts (search.py:1163-1256) ------------------------------------------
+    def region_random_sample_batch(self, region_model, prefixes, des, default_lens, uniforms=None, generator=None,
+                                   return_probs=False):
+        return self._regions().random_sample_batch(region_model, prefixes, des, default_lens, uniforms=uniforms,
+                                                   generator=generator, return_probs=return_probs)
+
+    def region_random_sample(self, region_model, trace_loc, trace_tim, des, default_len):
+        res = self.region_random_sample_batch(region_model, [(list(trace_loc), list(trace_tim))], [int(des)],
+                                              [int(default_len)])
+        return res['loc'][0], res['tim'][0]
+
+    def road_random_sample(self, gen_model, trace_loc, trace_tim, des, default_len):
+        return self.road_search.road_random_sample(gen_model, trace_loc, trace_tim, des, default_len)
 
     # -- batched two-stage generation ------------------------------------------------------------
     @torch.no_grad()
