@@ -33,6 +33,7 @@ BJ_DIMS = {   # our_model_generate.py:41-59
     'dis_weight': 0.45,
 }
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md, chip-level parameters
+PEAK_F16_MFMA_TFLOPS = 2500.0  # dense f16/bf16 matrix peak (MI355X_MICROARCH.md, matrix cores table)
 PEAK_HBM_GBS = 8000.0
 
 
@@ -49,6 +50,8 @@ def parse():
     ap.add_argument('--lmax', type=int, default=256)
     ap.add_argument('--streams', type=int, default=1, help='sub-engines (HIP streams) per GPU sharing the OD queue')
     ap.add_argument('--profile-every', type=int, default=8, help='event-bracket every k-th chunk of supersteps')
+    ap.add_argument('--lstm', default='split', choices=['split', 'fp32'],
+                    help='recurrent matmul: split-f16 three-pass matrix-core form (fp32-grade products) or plain fp32 MFMA')
     ap.add_argument('--cpu-seconds', type=float, default=20.0, help='CPU baseline budget (0 = skip)')
     return ap.parse_args()
 
@@ -129,6 +132,7 @@ def main():
     from ts_trajgen_amd.search import Searcher
     model, cfg = build_model(net, device)
     searcher = Searcher(device, net.adjacent_list, net.rid_gps, net.road_length, net.road_time_distribution)
+    searcher.state_format = 1 if args.lstm == 'split' else 0
     tables = model.tables()
     slots = args.slots
     if slots <= 0:
@@ -201,7 +205,9 @@ def main():
                 l = i - 2
                 K = hp if l == 0 else 2 * hp
                 flops = rows_per_launch * 2.0 * 4 * hp * K
-                k.update({'bound': 'mfma', 'achieved': flops / (avg_ms * 1e-3) / 1e12, 'peak': PEAK_F32_MFMA_TFLOPS,
+                # split form: three f16 matrix-core passes per algorithmic product -> a third of the dense f16 peak
+                peak = PEAK_F16_MFMA_TFLOPS / 3.0 if args.lstm == 'split' else PEAK_F32_MFMA_TFLOPS
+                k.update({'bound': 'mfma', 'achieved': flops / (avg_ms * 1e-3) / 1e12, 'peak': peak,
                           'unit': 'TFLOP/s'})
             elif nm.startswith('score'):
                 # own + ancestor top-layer h rows, gathered out_fc rows (+bias), factored H tables,
@@ -233,7 +239,7 @@ def main():
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': '%s, %d OD pairs per GPU, BJ model dims (hidden 256, 2-layer LSTM, GAT 5x256), '
                                    'random-init weights, max_step %d' % (net_name, args.ods, args.max_step),
-                       'od_pairs_per_gpu': args.ods, 'slots_in_flight': slots, 'streams': args.streams, 'parallelism': 'od-shard x%d' % world},
+                       'od_pairs_per_gpu': args.ods, 'slots_in_flight': slots, 'streams': args.streams, 'lstm': args.lstm, 'parallelism': 'od-shard x%d' % world},
             'expansions_per_s': exp_all / dt, 'expansions_per_od': exp_all / n_done,
             'reached_frac': float((status & 0xff == 1).mean()), 'fallback_frac': float((status & 0xff == 2).mean()),
             'avg_prefix_len_scored': avg_L, 'avg_candidates_scored': avg_C,

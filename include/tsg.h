@@ -117,6 +117,11 @@ typedef struct tsg_model {
   const float* pfrom;                /* [n_roads][10]  node_emb . emb_fc.weight[:, :F]^T */
   const float* pto;                  /* [n_roads][10]  node_emb . emb_fc.weight[:, F:]^T + emb_fc.bias */
   const float* hparams;              /* [42]: dis_fc.w[10], dis_fc.b[10], out_fc.w[20], out_fc.b, w1 */
+  /* Split-f16 images of whh0_t / wl_t for tsg_engine.state_format == 1 (may be null otherwise): every weight w
+   * as major = f16(w), minor = f16((w - major) * 2^11), tiled as [4Hp/128][K/32][major|minor][128 cols][32 k]
+   * f16 (the LDS image of one k-tile of one column tile is contiguous). */
+  const void* whh0_s;
+  const void* wl_s[TSG_MAX_LAYERS];
 } tsg_model;
 
 /* ------------------------------------------------------------------------------------------
@@ -225,6 +230,11 @@ typedef struct tsg_engine {
   int32_t up_levels;    float prune_spread;       /* |1-w1| + |w1| of the model (0 = only the all-closed rule): bound used to
                                                      skip expansions that cannot push anything, see tsg_search.hip */
   /* up_levels must be TSG_UP_LEVELS */
+  int32_t state_format; int32_t reserved0;        /* 0: h[l] holds fp32 and the recurrence runs on the fp32 matrix-core
+                                                     path; 1: h[l] holds one 32-bit word per element, low half
+                                                     major = f16(x), high half minor = f16((x - major) * 2^11), and the
+                                                     recurrence runs as three f16 matrix-core passes with fp32
+                                                     accumulation (products exact to 2^-22; see tsg_dense.hip) */
   float* h[TSG_MAX_LAYERS];                       /* [B*exp_cap][Hp] per layer */
   float* c[TSG_MAX_LAYERS];
   size_t state_bytes;                             /* bytes of EACH h[l] / c[l] */

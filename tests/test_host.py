@@ -44,8 +44,8 @@ def test_struct_sizes_match_header():
     """ctypes mirrors have the field counts/sizes the header implies (pointer = 8, int32 = 4)."""
     from ts_trajgen_amd import _lib
     assert ctypes.sizeof(_lib.Graph) == 8 + 8 * 8
-    assert ctypes.sizeof(_lib.Model) == 16 + (3 + 8 + 5) * 8
-    assert ctypes.sizeof(_lib.Engine) == 16 + 5 * 16 + 16 + 8 + 8 * 8 + 8 + 3 * 16 + 8
+    assert ctypes.sizeof(_lib.Model) == 16 + (3 + 8 + 5 + 5) * 8
+    assert ctypes.sizeof(_lib.Engine) == 16 + 5 * 16 + 16 + 8 + 8 + 8 * 8 + 8 + 3 * 16 + 8
     assert ctypes.sizeof(_lib.Rollout) == 16 + 11 * 8 + 8 * 8 + 8 + 4 * 8
 
 

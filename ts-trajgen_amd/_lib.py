@@ -36,7 +36,8 @@ class Model(C.Structure):
     _fields_ = [('n_roads', _i32), ('n_time', _i32), ('hp', _i32), ('n_layers', _i32),
                 ('xproj', _p), ('tproj', _p), ('whh0_t', _p),
                 ('wl_t', _p * TSG_MAX_LAYERS), ('bl', _p * TSG_MAX_LAYERS),
-                ('out_w', _p), ('out_b', _p), ('pfrom', _p), ('pto', _p), ('hparams', _p)]
+                ('out_w', _p), ('out_b', _p), ('pfrom', _p), ('pto', _p), ('hparams', _p),
+                ('whh0_s', _p), ('wl_s', _p * TSG_MAX_LAYERS)]
 
 
 class LstmStep(C.Structure):
@@ -66,7 +67,7 @@ class Engine(C.Structure):
                 ('slot_state', _p), ('slot_state_bytes', _sz), ('heap', _p), ('heap_bytes', _sz),
                 ('table', _p), ('table_bytes', _sz), ('nodes', _p), ('nodes_bytes', _sz),
                 ('exp_meta', _p), ('exp_meta_bytes', _sz), ('exp_up', _p), ('exp_up_bytes', _sz),
-                ('up_levels', _i32), ('prune_spread', C.c_float),
+                ('up_levels', _i32), ('prune_spread', C.c_float), ('state_format', _i32), ('reserved0', _i32),
                 ('h', _p * TSG_MAX_LAYERS), ('c', _p * TSG_MAX_LAYERS), ('state_bytes', _sz),
                 ('items', _p), ('items_bytes', _sz), ('cand_lp', _p), ('cand_lp_bytes', _sz),
                 ('shared_counters', _p), ('counters', _p), ('counters_bytes', _sz)]

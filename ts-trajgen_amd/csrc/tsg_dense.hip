@@ -296,6 +296,211 @@ __global__ __launch_bounds__(256, 2) void lstm_layer_kernel(LstmArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------ LSTM layer step, split-f16 form
+// Same contraction on the f16 matrix cores with fp32-grade products: every fp32 value x is carried as two
+// f16 numbers, major = f16(x) and minor = f16((x - major) * 2^11), i.e. 22 significant bits.  A product
+// a*b is accumulated (fp32 accumulators) as  2^11 a_maj b_maj + a_maj b_min + a_min b_maj  and scaled by
+// 2^-11 in the epilogue; the dropped a_min b_min term is 2^-22 relative.  v_mfma_f32_32x32x16_f16 runs 16 k
+// in 32 cycles where v_mfma_f32_32x32x2_f32 takes 64 cycles for 2 k: three passes cost 3/16 of the fp32 form.
+//   * hidden states live in HBM as one 32-bit word per element: major in the low half, minor in the high half
+//     (tsg_engine.state_format = 1); the epilogue writes that word, the attention reads it back as
+//     major + minor * 2^-11.  Cell states stay fp32.
+//   * A fragments come straight from the gathered state rows into registers (a wave's 32 rows are its own);
+//     within a 32-k tile lane half h owns k = 16h .. 16h+15 (one 64-byte run per row), the weights' LDS read
+//     offset applies the same permutation.
+//   * weights are pre-split and pre-tiled on the host as the LDS image [col tile][k tile][major|minor][128][32] f16.
+typedef _Float16 tsg_h8 __attribute__((ext_vector_type(8)));
+typedef unsigned tsg_u4 __attribute__((ext_vector_type(4)));
+
+#define SB_LD 40  // f16 per LDS row: 64 B of data + 16 B pad -> conflict-free ds_read_b128 over 32 columns
+
+struct __align__(16) TileB16 {
+  _Float16 major[BN][SB_LD];
+  _Float16 minor[BN][SB_LD];
+};
+
+__device__ __forceinline__ tsg_h8 tsg_pack_halves(unsigned w0, unsigned w1, unsigned w2, unsigned w3, unsigned w4,
+                                                  unsigned w5, unsigned w6, unsigned w7, unsigned sel) {
+  tsg_u4 p;
+  p.x = __builtin_amdgcn_perm(w1, w0, sel);
+  p.y = __builtin_amdgcn_perm(w3, w2, sel);
+  p.z = __builtin_amdgcn_perm(w5, w4, sel);
+  p.w = __builtin_amdgcn_perm(w7, w6, sel);
+  return __builtin_bit_cast(tsg_h8, p);
+}
+
+// fp32 -> state word (major | minor << 16)
+__device__ __forceinline__ unsigned tsg_split_word(float x) {
+  const bool tiny = fabsf(x) < 6.103515625e-05f;  // below the f16 normal range: everything goes to the minor part
+  const _Float16 mj = tiny ? (_Float16)0.0f : (_Float16)x;
+  const _Float16 mn = (_Float16)((x - (float)mj) * 2048.0f);
+  return (unsigned)__builtin_bit_cast(unsigned short, mj) | ((unsigned)__builtin_bit_cast(unsigned short, mn) << 16);
+}
+
+template <bool LAYER0>
+__global__ __launch_bounds__(256, 2) void lstm_layer_split_kernel(LstmArgs a) {
+  __shared__ TileB16 tb[2];
+  __shared__ long long s_prev[BM];
+  __shared__ long long s_out[BM];
+  __shared__ int s_rid[BM];
+  __shared__ int s_tc[BM];
+  const int n = a.n_rows_dev ? *a.n_rows_dev : a.n_rows_host;
+  const int hp = a.hp;
+  const int ct_n = hp / 32;
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, within = bid >> 3;
+  const int rowtile = (within / ct_n) * 8 + xcd;
+  const int coltile = within % ct_n;
+  const int row0 = rowtile * BM;
+  if (row0 >= n) return;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  if (tid < BM) {
+    const int m = row0 + tid;
+    long long pv = -1, ov = -1;
+    int rd = 0, tc = 0;
+    if (m < n) {
+      if (a.items) {
+        const int32_t* it = a.items + (size_t)m * IT_WORDS;
+        if (it[IT_SLOT] >= 0) {
+          const long long base = (long long)it[IT_SLOT] * a.exp_cap;
+          pv = it[IT_PARENT] >= 0 ? base + it[IT_PARENT] : -1;
+          ov = base + it[IT_EXP];
+          rd = it[IT_RID];
+          tc = it[IT_TCODE];
+        }
+      } else {
+        pv = a.prev_idx[m];
+        ov = a.out_idx[m];
+        if (LAYER0) {
+          rd = a.rid[m];
+          tc = a.tcode[m];
+        }
+      }
+    }
+    s_prev[tid] = pv;
+    s_out[tid] = ov;
+    s_rid[tid] = rd;
+    s_tc[tid] = tc;
+  }
+  __syncthreads();
+  const int K = LAYER0 ? hp : 2 * hp;
+  const int nkt = K / BK;
+  const int ldw = 4 * hp;
+  const int u = coltile * 32 + (lane & 31);
+  const int gcol = coltile * BN + (lane & 31);
+  const int lr = lane & 31, lh = lane >> 5;
+  tsg_f32x16 acc[4];
+  float cprev[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int r = wave * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+    const long long pv = s_prev[r];
+    cprev[i] = a.c[(size_t)(pv >= 0 ? pv : 0) * hp + u];
+  }
+  if (LAYER0) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int r = wave * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+      const float* xp = a.xproj + (size_t)s_rid[r] * ldw + gcol;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) acc[g][i] = xp[g * 32] * 2048.0f;
+    }
+  } else {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float bv = a.bias[gcol + g * 32] * 2048.0f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[g][i] = bv;
+    }
+  }
+  // this lane's A row: the state row of (wave's row lr) in the lower layer's output (k < hp) or in its own
+  // previous state (k >= hp for layers above 0, all k for layer 0)
+  const long long my_prev = s_prev[wave * 32 + lr], my_out = s_out[wave * 32 + lr];
+  const unsigned* hs_own = reinterpret_cast<const unsigned*>(a.h);
+  const unsigned* hs_below = reinterpret_cast<const unsigned*>(a.h_below);
+  const _Float16* wimg = reinterpret_cast<const _Float16*>(a.wt) + (size_t)coltile * nkt * (2 * BN * BK);
+  tsg_u4 na0, na1, na2, na3, nb0, nb1, nb2, nb3;  // prefetch registers (next k-tile)
+  unsigned amask;
+  auto gload = [&](int kt) {
+    const int k0 = kt * BK;
+    const bool below = !LAYER0 && (k0 < hp);
+    const long long ridx = below ? my_out : my_prev;
+    const unsigned* src = (below ? hs_below : hs_own) + (size_t)(ridx >= 0 ? ridx : 0) * hp + (below || LAYER0 ? k0 : k0 - hp) + 16 * lh;
+    amask = ridx >= 0 ? 0xffffffffu : 0u;
+    const tsg_u4* s4 = reinterpret_cast<const tsg_u4*>(src);
+    na0 = s4[0]; na1 = s4[1]; na2 = s4[2]; na3 = s4[3];
+    const tsg_u4* w4 = reinterpret_cast<const tsg_u4*>(wimg + (size_t)kt * (2 * BN * BK) + (size_t)tid * 32);
+    nb0 = w4[0]; nb1 = w4[1]; nb2 = w4[2]; nb3 = w4[3];
+  };
+  auto lstore = [&](int buf) {
+    _Float16* dst = (tid < BN) ? &tb[buf].major[tid][0] : &tb[buf].minor[tid - BN][0];
+    tsg_u4* d4 = reinterpret_cast<tsg_u4*>(dst);
+    d4[0] = nb0; d4[1] = nb1; d4[2] = nb2; d4[3] = nb3;
+  };
+  gload(0);
+  lstore(0);
+  tsg_u4 ca0 = na0 & amask, ca1 = na1 & amask, ca2 = na2 & amask, ca3 = na3 & amask;
+  __syncthreads();
+  const tsg_h8 scale = {(_Float16)2048.0f, (_Float16)2048.0f, (_Float16)2048.0f, (_Float16)2048.0f,
+                        (_Float16)2048.0f, (_Float16)2048.0f, (_Float16)2048.0f, (_Float16)2048.0f};
+  for (int kt = 0, cur = 0; kt < nkt; ++kt, cur ^= 1) {
+    const bool more = kt + 1 < nkt;
+    if (more) gload(kt + 1);
+    const TileB16& t = tb[cur];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const tsg_u4 w0 = s == 0 ? ca0 : ca2, w1 = s == 0 ? ca1 : ca3;
+      const tsg_h8 amaj = tsg_pack_halves(w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, 0x05040100u);
+      const tsg_h8 amin = tsg_pack_halves(w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, 0x07060302u);
+      const tsg_h8 amaj_s = amaj * scale;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int col = g * 32 + lr;
+        const tsg_h8 bmaj = *reinterpret_cast<const tsg_h8*>(&t.major[col][16 * lh + 8 * s]);
+        const tsg_h8 bmin = *reinterpret_cast<const tsg_h8*>(&t.minor[col][16 * lh + 8 * s]);
+        acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(amaj_s, bmaj, acc[g], 0, 0, 0);
+        acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(amaj, bmin, acc[g], 0, 0, 0);
+        acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(amin, bmaj, acc[g], 0, 0, 0);
+      }
+    }
+    if (more) {
+      lstore(cur ^ 1);
+      ca0 = na0 & amask; ca1 = na1 & amask; ca2 = na2 & amask; ca3 = na3 & amask;
+    }
+    __syncthreads();
+  }
+  float4 tq[4];
+  auto tload = [&](int i) {
+    const int r = wave * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+    const float* tp = a.tproj + (size_t)s_tc[r] * ldw + gcol;
+    return make_float4(tp[0], tp[32], tp[64], tp[96]);
+  };
+  if (LAYER0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) tq[i] = tload(i);
+  }
+  unsigned* hs_out = reinterpret_cast<unsigned*>(a.h);
+  const float inv = 1.0f / 2048.0f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int r = wave * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+    float4 tv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (LAYER0) {
+      tv = tq[i & 3];
+      if (i + 4 < 16) tq[i & 3] = tload(i + 4);
+    }
+    const float zi = acc[0][i] * inv + tv.x, zf = acc[1][i] * inv + tv.y;
+    const float zg = acc[2][i] * inv + tv.z, zo = acc[3][i] * inv + tv.w;
+    const float cp = s_prev[r] >= 0 ? cprev[i] : 0.0f;
+    const float cn = tsg_sigmoid(zf) * cp + tsg_sigmoid(zi) * tsg_tanh(zg);
+    const float hn = tsg_sigmoid(zo) * tsg_tanh(cn);
+    if (row0 + r >= n || s_out[r] < 0) continue;
+    const size_t o = (size_t)s_out[r] * hp + u;
+    a.c[o] = cn;
+    hs_out[o] = tsg_split_word(hn);
+  }
+}
+
 static int check_model_dims(const tsg_model* m) {
   if (!m) return TSG_E_INVALID;
   if (m->hp <= 0 || (m->hp % 64) != 0 || m->hp > 512) return TSG_E_INVALID;
@@ -306,7 +511,7 @@ static int check_model_dims(const tsg_model* m) {
 int tsg_launch_lstm_layer(const tsg_model* m, int layer, int max_rows, const int32_t* n_rows_dev, int n_rows_host,
                           const int64_t* prev_idx, const int64_t* out_idx, const int32_t* rid, const int32_t* tcode,
                           const int32_t* items, int exp_cap, const float* h_below, float* h, float* c,
-                          hipStream_t stream) {
+                          hipStream_t stream, int split) {
   LstmArgs a;
   a.layer = layer;
   a.hp = m->hp;
@@ -321,7 +526,8 @@ int tsg_launch_lstm_layer(const tsg_model* m, int layer, int max_rows, const int
   a.h_below = h_below;
   a.h = h;
   a.c = c;
-  a.wt = layer == 0 ? m->whh0_t : m->wl_t[layer];
+  a.wt = split ? reinterpret_cast<const float*>(layer == 0 ? m->whh0_s : m->wl_s[layer])
+               : (layer == 0 ? m->whh0_t : m->wl_t[layer]);
   a.xproj = m->xproj;
   a.tproj = m->tproj;
   a.bias = layer == 0 ? nullptr : m->bl[layer];
@@ -331,7 +537,12 @@ int tsg_launch_lstm_layer(const tsg_model* m, int layer, int max_rows, const int
   if (max_rows <= 0) return 0;
   const int rowtiles = tsg_cdiv(max_rows, BM);
   const int grid = 8 * tsg_cdiv(rowtiles, 8) * (m->hp / 32);
-  if (layer == 0)
+  if (split) {
+    if (layer == 0)
+      hipLaunchKernelGGL(lstm_layer_split_kernel<true>, dim3(grid), dim3(256), 0, stream, a);
+    else
+      hipLaunchKernelGGL(lstm_layer_split_kernel<false>, dim3(grid), dim3(256), 0, stream, a);
+  } else if (layer == 0)
     hipLaunchKernelGGL(lstm_layer_kernel<true>, dim3(grid), dim3(256), 0, stream, a);
   else
     hipLaunchKernelGGL(lstm_layer_kernel<false>, dim3(grid), dim3(256), 0, stream, a);
@@ -346,5 +557,5 @@ extern "C" int tsg_lstm_step_batched(const tsg_model* m, const tsg_lstm_step* s,
   if (!s->prev_idx || !s->out_idx) return TSG_E_INVALID;
   if (s->layer == 0 && (!s->rid || !s->tcode)) return TSG_E_INVALID;
   return tsg_launch_lstm_layer(m, s->layer, s->n_rows_host, s->n_rows_dev, s->n_rows_host, s->prev_idx, s->out_idx,
-                               s->rid, s->tcode, nullptr, 0, s->h_below, s->h, s->c, (hipStream_t)stream);
+                               s->rid, s->tcode, nullptr, 0, s->h_below, s->h, s->c, (hipStream_t)stream, 0);
 }

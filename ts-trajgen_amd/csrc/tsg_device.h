@@ -50,7 +50,17 @@ __device__ inline double tsg_dev_geodesic_m(const double* __restrict__ p1, const
 // A state row (hp floats) spread over the wave.  JT = compile-time register count per lane.
 // hp == 256 (JT == 4, J == 4): lane owns elements 4*lane .. 4*lane+3 (one dwordx4 per row);
 // otherwise lane owns elements lane + 64*j.  Every vector that meets in a dot product uses the same map.
-template <int JT>
+// SPLIT rows hold the engine's state words (tsg_engine.state_format == 1): low half major = f16(x), high half
+// minor = f16((x - major) * 2^11); the value read back is major + minor * 2^-11.
+typedef _Float16 tsg_h2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float tsg_state_value(float word_as_float) {
+  // one v_dot2_f32_f16: major * 1 + minor * 2^-11 with fp32 accumulation (both products are exact)
+  const tsg_h2 w = __builtin_bit_cast(tsg_h2, word_as_float);
+  const tsg_h2 k = {(_Float16)1.0f, (_Float16)0.00048828125f};
+  return __builtin_amdgcn_fdot2(w, k, 0.0f, false);
+}
+
+template <int JT, bool SPLIT = false>
 __device__ __forceinline__ void load_row(const float* __restrict__ row, float out[JT], int J, int lane) {
   if (JT == 4 && J == 4) {
     const float4 v = *reinterpret_cast<const float4*>(row + 4 * lane);
@@ -61,6 +71,10 @@ __device__ __forceinline__ void load_row(const float* __restrict__ row, float ou
   } else {
 #pragma unroll
     for (int j = 0; j < JT; ++j) out[j] = (j < J) ? row[lane + 64 * j] : 0.0f;
+  }
+  if (SPLIT) {
+#pragma unroll
+    for (int j = 0; j < JT; ++j) out[j] = tsg_state_value(out[j]);
   }
 }
 
@@ -82,6 +96,8 @@ __device__ __forceinline__ void attn_init(AttnAcc<JT>& s) {
 // Attention over key rows in groups of 4: attn_load4 issues the (independent, coalesced) row loads of a
 // group, attn_fold4 folds a loaded group into the running online softmax.  The caller loads group g+1
 // before folding group g, so eight rows per wave are in flight.  rows[u] == nullptr marks an absent row.
+// (split state rows are loaded RAW here and decoded in attn_fold4, so that decoding never pulls the wait for a
+// group's loads in front of the previous group's fold)
 template <int JT>
 __device__ __forceinline__ void attn_load4(float key[4][JT], const float* const rows[4], int J, int lane) {
 #pragma unroll
@@ -95,9 +111,15 @@ __device__ __forceinline__ void attn_load4(float key[4][JT], const float* const 
   }
 }
 
-template <int JT>
-__device__ __forceinline__ void attn_fold4(AttnAcc<JT>& s, const float key[4][JT], unsigned present,
+template <int JT, bool SPLIT = false>
+__device__ __forceinline__ void attn_fold4(AttnAcc<JT>& s, float key[4][JT], unsigned present,
                                            const float q[JT]) {
+  if (SPLIT) {  // decode in place
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int j = 0; j < JT; ++j) key[u][j] = tsg_state_value(key[u][j]);
+  }
   float part[4];
 #pragma unroll
   for (int u = 0; u < 4; ++u) {

@@ -11,7 +11,7 @@
 int tsg_launch_lstm_layer(const tsg_model* m, int layer, int max_rows, const int32_t* n_rows_dev, int n_rows_host,
                           const int64_t* prev_idx, const int64_t* out_idx, const int32_t* rid, const int32_t* tcode,
                           const int32_t* items, int exp_cap, const float* h_below, float* h, float* c,
-                          hipStream_t stream);
+                          hipStream_t stream, int split);
 
 // =====================================================================================
 // explicit-row scoring: GeneratorV4.predict (generator_v4.py:56-72) for (prefix, candidates, dis) rows
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void cand_dis_kernel(EngineDev D, int superste
 // (anc[e][0] = parent, anc[e][i] = anc[parent][i-1]) and then already holds, one per lane, the slots whose
 // top-layer hidden rows the attention needs: no pointer chase, the key rows are independent coalesced
 // loads.  Chains longer than 64 hop through anc[.][63] once per 64 rows.
-template <int JT>
+template <int JT, bool SPLIT>
 __global__ __launch_bounds__(256) void score_frontier_kernel(tsg_model m, EngineDev D, int superstep) {
   const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) void score_frontier_kernel(tsg_model m, Engine
   const int32_t* em = D.e.exp_meta + (size_t)b * D.e.exp_cap * EM_WORDS;
   const int depth = em[(size_t)e * EM_WORDS + EM_DEPTH];  // = number of rows on the ancestor chain incl. e
   float q[JT];
-  load_row<JT>(htop + (size_t)e * hp, q, J, lane);
+  load_row<JT, SPLIT>(htop + (size_t)e * hp, q, J, lane);
   AttnAcc<JT> acc;
   attn_init(acc);
   int anchor = e;   // the (64 * chunk)-th ancestor
@@ -172,11 +172,11 @@ __global__ __launch_bounds__(256) void score_frontier_kernel(tsg_model m, Engine
 #if TSG_ABLATE == 2
       if (i == 0)
 #endif
-      attn_fold4<JT>(acc, keyA, presA, q);
+      attn_fold4<JT, SPLIT>(acc, keyA, presA, q);
       if (i + 4 < n) {
         if (i + 8 < n) issue(i + 8, keyA, presA);
 #if TSG_ABLATE != 2
-        attn_fold4<JT>(acc, keyB, presB, q);
+        attn_fold4<JT, SPLIT>(acc, keyB, presB, q);
 #endif
       }
     }
@@ -208,14 +208,22 @@ static void launch_cand_dis(const EngineDev& D, int superstep, hipStream_t s) {
   hipLaunchKernelGGL(cand_dis_kernel, dim3(tsg_cdiv(threads, 256)), dim3(256), 0, s, D, superstep);
 }
 
-static void launch_score_frontier(const tsg_model* m, const EngineDev& D, int superstep, hipStream_t s) {
+template <bool SPLIT>
+static void launch_score_frontier_t(const tsg_model* m, const EngineDev& D, int superstep, hipStream_t s) {
   const dim3 grid(tsg_cdiv(D.e.slots, 4)), blk(256);
   switch (jt_for(m->hp)) {
-    case 1: hipLaunchKernelGGL(score_frontier_kernel<1>, grid, blk, 0, s, *m, D, superstep); break;
-    case 2: hipLaunchKernelGGL(score_frontier_kernel<2>, grid, blk, 0, s, *m, D, superstep); break;
-    case 4: hipLaunchKernelGGL(score_frontier_kernel<4>, grid, blk, 0, s, *m, D, superstep); break;
-    default: hipLaunchKernelGGL(score_frontier_kernel<8>, grid, blk, 0, s, *m, D, superstep); break;
+    case 1: hipLaunchKernelGGL((score_frontier_kernel<1, SPLIT>), grid, blk, 0, s, *m, D, superstep); break;
+    case 2: hipLaunchKernelGGL((score_frontier_kernel<2, SPLIT>), grid, blk, 0, s, *m, D, superstep); break;
+    case 4: hipLaunchKernelGGL((score_frontier_kernel<4, SPLIT>), grid, blk, 0, s, *m, D, superstep); break;
+    default: hipLaunchKernelGGL((score_frontier_kernel<8, SPLIT>), grid, blk, 0, s, *m, D, superstep); break;
   }
+}
+
+static void launch_score_frontier(const tsg_model* m, const EngineDev& D, int superstep, hipStream_t s) {
+  if (D.e.state_format)
+    launch_score_frontier_t<true>(m, D, superstep, s);
+  else
+    launch_score_frontier_t<false>(m, D, superstep, s);
 }
 
 // =====================================================================================
@@ -798,6 +806,12 @@ static int check_engine(const tsg_model* m, const tsg_graph* g, const tsg_od_bat
     if (m->n_roads < g->n_roads) return TSG_E_INVALID;
     if (!g->geo && !g->dist_table) return TSG_E_INVALID;
     if (e->up_levels != TSG_UP_LEVELS) return TSG_E_INVALID;
+    if (e->state_format != 0 && e->state_format != 1) return TSG_E_INVALID;
+    if (e->state_format == 1) {
+      if (!m->whh0_s) return TSG_E_INVALID;
+      for (int l = 1; l < m->n_layers; ++l)
+        if (!m->wl_s[l]) return TSG_E_INVALID;
+    }
     if (!e->exp_up || e->exp_up_bytes < B * e->exp_cap * (size_t)e->up_levels * 4) return TSG_E_TOO_SMALL;
     for (int l = 0; l < m->n_layers; ++l)
       if (!e->h[l] || !e->c[l] || e->state_bytes < B * e->exp_cap * (size_t)m->hp * 4) return TSG_E_TOO_SMALL;
@@ -871,7 +885,7 @@ extern "C" int tsg_engine_run(const tsg_model* m, const tsg_graph* g, const tsg_
     TSG_LAUNCH_CHECK();
     for (int l = 0; l < m->n_layers; ++l) {
       rc = tsg_launch_lstm_layer(m, l, e->slots, nullptr, e->slots, nullptr, nullptr, nullptr, nullptr, e->items, e->exp_cap,
-                                 l > 0 ? e->h[l - 1] : nullptr, e->h[l], e->c[l], s);
+                                 l > 0 ? e->h[l - 1] : nullptr, e->h[l], e->c[l], s, e->state_format);
       if (rc) return rc;
     }
     launch_score_frontier(m, D, ss, s);
@@ -956,7 +970,7 @@ extern "C" int tsg_engine_run_profiled(const tsg_model* m, const tsg_graph* g, c
     for (int l = 0; l < m->n_layers && rc == 0; ++l) {
       (void)hipEventRecord(ev[q++], s);
       rc = tsg_launch_lstm_layer(m, l, e->slots, nullptr, e->slots, nullptr, nullptr, nullptr, nullptr, e->items, e->exp_cap,
-                                 l > 0 ? e->h[l - 1] : nullptr, e->h[l], e->c[l], s);
+                                 l > 0 ? e->h[l - 1] : nullptr, e->h[l], e->c[l], s, e->state_format);
       (void)hipEventRecord(ev[q++], s);
     }
     (void)hipEventRecord(ev[q++], s);

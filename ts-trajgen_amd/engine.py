@@ -61,6 +61,25 @@ def gemm(a, bt, bias=None):
     return out
 
 
+def split_f16_image(w_t):
+    """[K][4Hp] fp32 weights -> the split-f16 LDS image of tsg_model.whh0_s / wl_s:
+    major = f16(w), minor = f16((w - major) * 2^11) (values below the f16 normal range go entirely to the minor
+    part), tiled [4Hp/128][K/32][major|minor][128 cols][32 k]."""
+    K, N = w_t.shape
+    if K % 32 or N % 128:
+        raise ValueError('split image needs K % 32 == 0 and N % 128 == 0')
+    if float(w_t.abs().max()) >= 6.0e4:
+        raise ValueError('LSTM weight outside the f16 range: use state_format=0')
+    tiny = w_t.abs() < 2.0 ** -14
+    major = torch.where(tiny, torch.zeros_like(w_t), w_t).to(torch.float16)
+    minor = ((w_t - major.float()) * 2048.0).to(torch.float16)
+
+    def tile(x):
+        return x.t().reshape(N // 128, 128, K // 32, 32).permute(0, 2, 1, 3)
+
+    return torch.stack([tile(major), tile(minor)], dim=2).contiguous()
+
+
 class ModelTables(object):
     """Device tables of one GeneratorV4 (generator_v4.py:16-29) in the layout of `tsg_model`."""
 
@@ -91,6 +110,10 @@ class ModelTables(object):
                 self.wl_t[l] = torch.cat([top, bot], dim=0).contiguous()
                 self.bl[l] = _permute_cols((sd['lstm.bias_ih_l%d' % l] + sd['lstm.bias_hh_l%d' % l]).unsqueeze(0),
                                            H, hp).squeeze(0).contiguous()
+            self.whh0_s = split_f16_image(self.whh0_t)
+            self.wl_s = [None] * _lib.TSG_MAX_LAYERS
+            for l in range(1, nl):
+                self.wl_s[l] = split_f16_image(self.wl_t[l])
             ow = sd['out_fc.weight']                                        # (road_num, H)
             self.out_w = torch.zeros((ow.shape[0], hp), dtype=torch.float32, device=dev)
             self.out_w[:, :H] = ow
@@ -118,6 +141,8 @@ class ModelTables(object):
         for l in range(1, nl):
             m.wl_t[l] = self.wl_t[l].data_ptr()
             m.bl[l] = self.bl[l].data_ptr()
+            m.wl_s[l] = self.wl_s[l].data_ptr()
+        m.whh0_s = _lib.ptr(self.whh0_s)
         m.out_w, m.out_b = _lib.ptr(self.out_w), _lib.ptr(self.out_b)
         m.pfrom, m.pto, m.hparams = _lib.ptr(self.pfrom), _lib.ptr(self.pto), _lib.ptr(self.hparams)
         self.c_model = m
@@ -300,7 +325,8 @@ class AStarEngine(object):
     while one sub-engine is in its latency-bound frontier / scoring kernels, another keeps the matrix cores
     busy with its LSTM step.  Workspaces are disjoint slices of the same tensors."""
 
-    def __init__(self, tables, graph, slots, max_step, max_prefix=1, lmax=256, streams=1, prune=True, use_graph=True):
+    def __init__(self, tables, graph, slots, max_step, max_prefix=1, lmax=256, streams=1, prune=True, use_graph=True,
+                 state_format=1):
         self.tables, self.graph = tables, graph
         dev = self.device = tables.device
         n = graph.num_roads
@@ -345,12 +371,14 @@ class AStarEngine(object):
             e.state_bytes = sb * self.exp_cap * hp * 4
             e.up_levels = self.up_levels
             e.prune_spread = self.prune_spread
+            e.state_format = int(state_format)
             e.counters = self.counters[k].data_ptr()
             e.counters_bytes = 64
             e.shared_counters = self.counters[streams].data_ptr()
             self.c_engines.append(e)
         self.side_streams = [torch.cuda.Stream(device=dev) for _ in range(streams)]
         self.use_graph = bool(use_graph)
+        self.state_format = int(state_format)
         self._pinned = [torch.zeros((streams + 1, 16), dtype=i32).pin_memory() for _ in range(2)]
         self.last_stats = {}
 

@@ -28,6 +28,10 @@ def _auto_slots(tables, graph, max_step, max_prefix, n_od, device, budget_frac=0
 
 
 class Searcher(object):
+    # 1: hidden states as split-f16 words, recurrence on the f16 matrix cores in three passes (fp32-grade
+    # products, include/tsg.h tsg_engine.state_format); 0: plain fp32 states on the fp32 matrix-core path
+    state_format = 1
+
     def __init__(self, device, adjacent_list, road_center_gps=None, road_length=None, road_time_distribution=None):
         self.device = torch.device(device)
         self.adjacent_list = adjacent_list
@@ -47,11 +51,12 @@ class Searcher(object):
 
     def _engine(self, gen_model, slots, max_step, max_prefix, lmax, streams=1):
         tables = gen_model.tables()
-        key = (id(tables), slots, max_step, max_prefix, lmax, streams)
+        key = (id(tables), slots, max_step, max_prefix, lmax, streams, self.state_format)
         eng = self._engines.get(key)
         if eng is None:
             self._engines.clear()       # one engine's workspaces at a time
-            eng = AStarEngine(tables, self.graph(), slots, max_step, max_prefix, lmax, streams)
+            eng = AStarEngine(tables, self.graph(), slots, max_step, max_prefix, lmax, streams,
+                              state_format=self.state_format)
             self._engines[key] = eng
         return eng
 
