@@ -27,3 +27,31 @@ print('span ms', (t1 - t0) / 1e6, 'union busy ms', busy / 1e6, 'sum of kernels m
 print('queues', sorted(set(r[3] for r in rows)), 'streams', sorted(set(r[4] for r in rows)))
 for n, (d, c) in sorted(tot.items(), key=lambda x: -x[1][0])[:10]:
     print('%-42s n=%7d total %9.2f ms avg %8.2f us' % (n, c, d / 1e6, d / c / 1e3))
+if len(sys.argv) > 2:
+    mid = len(rows) // 2
+    base = rows[mid][0]
+    for s, e, n, q, st in rows[mid:mid + int(sys.argv[2])]:
+        print('q%s %-28s start %9.1f us  dur %7.1f us' % (q, n[:28], (s - base) / 1e3, (e - s) / 1e3))
+runs, last, n = [], None, 0
+for s, e, nme, q, st in rows:
+    if q != last:
+        if last is not None:
+            runs.append(n)
+        last, n = q, 0
+    n += 1
+runs.append(n)
+import statistics
+print('queue runs: count', len(runs), 'median length', statistics.median(runs), 'max', max(runs))
+per_q = defaultdict(int)
+for s, e, nme, q, st in rows:
+    per_q[q] += e - s
+print('busy per queue ms', {q: v / 1e6 for q, v in per_q.items()})
+seen = {}
+with open(sys.argv[1]) as f:
+    for r in csv.DictReader(f):
+        k = r['Kernel_Name'].split('(')[0][:40]
+        if k not in seen:
+            seen[k] = (r['LDS_Block_Size'], r['Scratch_Size'], r['VGPR_Count'], r['Accum_VGPR_Count'], r['SGPR_Count'],
+                       r['Workgroup_Size_X'], r['Grid_Size_X'])
+for k, v in seen.items():
+    print('%-42s lds %s scratch %s vgpr %s agpr %s sgpr %s wg %s grid %s' % ((k,) + v))

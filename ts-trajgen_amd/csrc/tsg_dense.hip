@@ -419,16 +419,21 @@ __global__ __launch_bounds__(256, 2) void lstm_layer_split_kernel(LstmArgs a) {
   const unsigned* hs_own = reinterpret_cast<const unsigned*>(a.h);
   const unsigned* hs_below = reinterpret_cast<const unsigned*>(a.h_below);
   const _Float16* wimg = reinterpret_cast<const _Float16*>(a.wt) + (size_t)coltile * nkt * (2 * BN * BK);
-  tsg_u4 na0, na1, na2, na3, nb0, nb1, nb2, nb3;  // prefetch registers (next k-tile)
-  unsigned amask;
-  auto gload = [&](int kt) {
-    const int k0 = kt * BK;
-    const bool below = !LAYER0 && (k0 < hp);
-    const long long ridx = below ? my_out : my_prev;
-    const unsigned* src = (below ? hs_below : hs_own) + (size_t)(ridx >= 0 ? ridx : 0) * hp + (below || LAYER0 ? k0 : k0 - hp) + 16 * lh;
-    amask = ridx >= 0 ? 0xffffffffu : 0u;
-    const tsg_u4* s4 = reinterpret_cast<const tsg_u4*>(src);
-    na0 = s4[0]; na1 = s4[1]; na2 = s4[2]; na3 = s4[3];
+  // prefetch registers: the gathered state rows (HBM latency) run two k-tiles ahead, the weights (L2) one
+  tsg_u4 na0, na1, na2, na3, ma0, ma1, ma2, ma3, nb0, nb1, nb2, nb3;
+  unsigned amask_n = 0, amask_m = 0;
+#define TSG_GLOAD_ROWS(KT, R0, R1, R2, R3, MASK)                                                              \
+  {                                                                                                          \
+    const int k0_ = (KT) * BK;                                                                               \
+    const bool below_ = !LAYER0 && (k0_ < hp);                                                               \
+    const long long ridx_ = below_ ? my_out : my_prev;                                                       \
+    const unsigned* src_ = (below_ ? hs_below : hs_own) + (size_t)(ridx_ >= 0 ? ridx_ : 0) * hp +            \
+                           ((below_ || LAYER0) ? k0_ : k0_ - hp) + 16 * lh;                                  \
+    MASK = ridx_ >= 0 ? 0xffffffffu : 0u;                                                                    \
+    const tsg_u4* s4_ = reinterpret_cast<const tsg_u4*>(src_);                                               \
+    R0 = s4_[0]; R1 = s4_[1]; R2 = s4_[2]; R3 = s4_[3];                                                      \
+  }
+  auto gload_w = [&](int kt) {
     const tsg_u4* w4 = reinterpret_cast<const tsg_u4*>(wimg + (size_t)kt * (2 * BN * BK) + (size_t)tid * 32);
     nb0 = w4[0]; nb1 = w4[1]; nb2 = w4[2]; nb3 = w4[3];
   };
@@ -437,15 +442,23 @@ __global__ __launch_bounds__(256, 2) void lstm_layer_split_kernel(LstmArgs a) {
     tsg_u4* d4 = reinterpret_cast<tsg_u4*>(dst);
     d4[0] = nb0; d4[1] = nb1; d4[2] = nb2; d4[3] = nb3;
   };
-  gload(0);
+  TSG_GLOAD_ROWS(0, na0, na1, na2, na3, amask_n)
+  gload_w(0);
+  if (nkt > 1) TSG_GLOAD_ROWS(1, ma0, ma1, ma2, ma3, amask_m)
   lstore(0);
-  tsg_u4 ca0 = na0 & amask, ca1 = na1 & amask, ca2 = na2 & amask, ca3 = na3 & amask;
+  tsg_u4 ca0 = na0 & amask_n, ca1 = na1 & amask_n, ca2 = na2 & amask_n, ca3 = na3 & amask_n;
   __syncthreads();
   const tsg_h8 scale = {(_Float16)2048.0f, (_Float16)2048.0f, (_Float16)2048.0f, (_Float16)2048.0f,
                         (_Float16)2048.0f, (_Float16)2048.0f, (_Float16)2048.0f, (_Float16)2048.0f};
   for (int kt = 0, cur = 0; kt < nkt; ++kt, cur ^= 1) {
     const bool more = kt + 1 < nkt;
-    if (more) gload(kt + 1);
+    // rows of tile kt+1 are in flight in m*; move them to n* and start tile kt+2
+    if (more) {
+      na0 = ma0; na1 = ma1; na2 = ma2; na3 = ma3;
+      amask_n = amask_m;
+      gload_w(kt + 1);
+    }
+    if (kt + 2 < nkt) TSG_GLOAD_ROWS(kt + 2, ma0, ma1, ma2, ma3, amask_m)
     const TileB16& t = tb[cur];
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
@@ -465,7 +478,7 @@ __global__ __launch_bounds__(256, 2) void lstm_layer_split_kernel(LstmArgs a) {
     }
     if (more) {
       lstore(cur ^ 1);
-      ca0 = na0 & amask; ca1 = na1 & amask; ca2 = na2 & amask; ca3 = na3 & amask;
+      ca0 = na0 & amask_n; ca1 = na1 & amask_n; ca2 = na2 & amask_n; ca3 = na3 & amask_n;
     }
     __syncthreads();
   }

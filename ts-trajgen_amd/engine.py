@@ -6,6 +6,7 @@ completion counter.  PyTorch is used for device memory, streams and one-off layo
 """
 import ctypes as C
 import math
+import os
 
 import numpy as np
 import torch
@@ -377,7 +378,7 @@ class AStarEngine(object):
             e.shared_counters = self.counters[streams].data_ptr()
             self.c_engines.append(e)
         self.side_streams = [torch.cuda.Stream(device=dev) for _ in range(streams)]
-        self.use_graph = bool(use_graph)
+        self.use_graph = bool(use_graph) and os.environ.get('TSG_NO_GRAPH', '') != '1'   # env: diagnostics only
         self.state_format = int(state_format)
         self._pinned = [torch.zeros((streams + 1, 16), dtype=i32).pin_memory() for _ in range(2)]
         self.last_stats = {}
