@@ -92,6 +92,10 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise RuntimeError('libtsg.so is not built (%s). Run `python -c "import __graft_entry__ as g; g.build()"` '
                            'or `make -C ts-trajgen_amd/csrc`. There is no CPU fallback.' % LIB_PATH)
+    # torch ships its own libamdhip64 (soname libamdhip64.so.7).  Loaded first, it satisfies libtsg's NEEDED entry
+    # and both share one HIP runtime; loaded second, the process ends up with two runtimes and every launch
+    # from libtsg fails with hipErrorNoDevice.
+    import torch  # noqa: F401
     L = C.CDLL(LIB_PATH)
     for name in EXPORTS:
         if not hasattr(L, name):
