@@ -230,11 +230,15 @@ typedef struct tsg_engine {
   int32_t up_levels;    float prune_spread;       /* |1-w1| + |w1| of the model (0 = only the all-closed rule): bound used to
                                                      skip expansions that cannot push anything, see tsg_search.hip */
   /* up_levels must be TSG_UP_LEVELS */
-  int32_t state_format; int32_t reserved0;        /* 0: h[l] holds fp32 and the recurrence runs on the fp32 matrix-core
+  int32_t state_format; int32_t max_pops;         /* state_format 0: h[l] holds fp32 and the recurrence runs on the fp32 matrix-core
                                                      path; 1: h[l] holds one 32-bit word per element, low half
                                                      major = f16(x), high half minor = f16((x - major) * 2^11), and the
                                                      recurrence runs as three f16 matrix-core passes with fp32
-                                                     accumulation (products exact to 2^-22; see tsg_dense.hip) */
+                                                     accumulation (products exact to 2^-22; see tsg_dense.hip).
+                                                     max_pops: a search that has popped this many queue entries in one
+                                                     superstep without finding a node to expand yields until the next
+                                                     superstep (0 = no limit); bounds the launch time by the typical,
+                                                     not the worst, search; results do not depend on it */
   float* h[TSG_MAX_LAYERS];                       /* [B*exp_cap][Hp] per layer */
   float* c[TSG_MAX_LAYERS];
   size_t state_bytes;                             /* bytes of EACH h[l] / c[l] */

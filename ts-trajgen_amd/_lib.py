@@ -67,7 +67,7 @@ class Engine(C.Structure):
                 ('slot_state', _p), ('slot_state_bytes', _sz), ('heap', _p), ('heap_bytes', _sz),
                 ('table', _p), ('table_bytes', _sz), ('nodes', _p), ('nodes_bytes', _sz),
                 ('exp_meta', _p), ('exp_meta_bytes', _sz), ('exp_up', _p), ('exp_up_bytes', _sz),
-                ('up_levels', _i32), ('prune_spread', C.c_float), ('state_format', _i32), ('reserved0', _i32),
+                ('up_levels', _i32), ('prune_spread', C.c_float), ('state_format', _i32), ('max_pops', _i32),
                 ('h', _p * TSG_MAX_LAYERS), ('c', _p * TSG_MAX_LAYERS), ('state_bytes', _sz),
                 ('items', _p), ('items_bytes', _sz), ('cand_lp', _p), ('cand_lp_bytes', _sz),
                 ('shared_counters', _p), ('counters', _p), ('counters_bytes', _sz)]

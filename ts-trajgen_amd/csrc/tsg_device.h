@@ -155,6 +155,39 @@ __device__ __forceinline__ void attn_fold4(AttnAcc<JT>& s, float key[4][JT], uns
   s.m = mn;
 }
 
+// H logit of one candidate: factored emb_fc + dis_fc + out_fc (distance_gat_fc.py:129-133)
+__device__ __forceinline__ float tsg_h_logit(const tsg_model& m, int cand, int des, float dis) {
+  const float* hpar = m.hparams;
+  const float* pf = m.pfrom + (size_t)cand * TSG_H_HIDDEN;
+  const float* pt = m.pto + (size_t)des * TSG_H_HIDDEN;
+  float acc = hpar[40];
+#pragma unroll
+  for (int j = 0; j < TSG_H_HIDDEN; ++j) acc += hpar[20 + j] * fmaxf(pf[j] + pt[j], 0.0f);
+#pragma unroll
+  for (int j = 0; j < TSG_H_HIDDEN; ++j) acc += hpar[30 + j] * fmaxf(hpar[j] * dis + hpar[10 + j], 0.0f);
+  return acc;
+}
+
+// softmax((1-w1) softmax(G) + w1 softmax(H)) over the lanes with `on` set (generator_v4.py:46-54,71-72);
+// one candidate per lane, whole wave participates.
+__device__ __forceinline__ float tsg_mix_softmax(const tsg_model& m, float g_logit, float h_logit, bool on, float* pg,
+                                                 float* ph) {
+  const float w1 = m.hparams[41];
+  const float gmax = tsg_wave_max(on ? g_logit : -INFINITY);
+  const float ge = on ? expf(g_logit - gmax) : 0.0f;
+  const float g = ge / tsg_wave_sum(ge);
+  const float hmax = tsg_wave_max(on ? h_logit : -INFINITY);
+  const float he = on ? expf(h_logit - hmax) : 0.0f;
+  const float h = he / tsg_wave_sum(he);
+  const float mix = on ? (1.0f - w1) * g + w1 * h : -INFINITY;
+  const float mmax = tsg_wave_max(mix);
+  const float me = on ? expf(mix - mmax) : 0.0f;
+  const float f = me / tsg_wave_sum(me);
+  if (pg) *pg = g;
+  if (ph) *ph = h;
+  return f;
+}
+
 // Score up to 64 candidates of one row.  Lane i < ncand returns the probability f_i of
 // softmax((1-w1) softmax(G) + w1 softmax(H))  (generator_v4.py:46-54,71-72); also the two inner
 // softmaxes through pg/ph.  `pooled` = attention-pooled hidden in the load_row lane map.
@@ -186,31 +219,9 @@ __device__ __forceinline__ float score_row(const tsg_model& m, const float poole
     for (int u = 0; u < 4; ++u)
       if (lane == c0 + u && c0 + u < ncand) g_logit = part[u] + m.out_b[cid[u]];
   }
-  // H: factored emb_fc + dis_fc + out_fc (distance_gat_fc.py:129-133)
-  float h_logit = -INFINITY;
-  if (lane < ncand) {
-    const float* hpar = m.hparams;
-    const float* pf = m.pfrom + (size_t)my_cand * TSG_H_HIDDEN;
-    const float* pt = m.pto + (size_t)des * TSG_H_HIDDEN;
-    float acc = hpar[40];
-#pragma unroll
-    for (int j = 0; j < TSG_H_HIDDEN; ++j) acc += hpar[20 + j] * fmaxf(pf[j] + pt[j], 0.0f);
-#pragma unroll
-    for (int j = 0; j < TSG_H_HIDDEN; ++j) acc += hpar[30 + j] * fmaxf(hpar[j] * my_dis + hpar[10 + j], 0.0f);
-    h_logit = acc;
-  }
-  const float w1 = m.hparams[41];
-  const bool on = lane < ncand;
-  const float gmax = tsg_wave_max(g_logit);
-  const float ge = on ? expf(g_logit - gmax) : 0.0f;
-  const float g = ge / tsg_wave_sum(ge);
-  const float hmax = tsg_wave_max(h_logit);
-  const float he = on ? expf(h_logit - hmax) : 0.0f;
-  const float h = he / tsg_wave_sum(he);
-  const float mix = on ? (1.0f - w1) * g + w1 * h : -INFINITY;
-  const float mmax = tsg_wave_max(mix);
-  const float me = on ? expf(mix - mmax) : 0.0f;
-  const float f = me / tsg_wave_sum(me);
+  const float h_logit = lane < ncand ? tsg_h_logit(m, my_cand, des, my_dis) : -INFINITY;
+  float g, h;
+  const float f = tsg_mix_softmax(m, g_logit, h_logit, lane < ncand, &g, &h);
   if (pg) *pg = g;
   if (ph) *ph = h;
   return f;

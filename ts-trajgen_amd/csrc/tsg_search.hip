@@ -394,6 +394,9 @@ __global__ __launch_bounds__(256) void frontier_kernel(EngineDev D, int superste
   float best_lp = __int_as_float(S[SS_BEST_LP]);
   int best_parent = S[SS_BEST_PARENT], best_rid = S[SS_BEST_RID], best_tcode = S[SS_BEST_TCODE];
   int have_best = S[SS_HAVE_BEST], npop = S[SS_NPOP];
+  // statistics: kept in registers for the launch (a read-modify-write on S[] is a dependent round trip each)
+  int st_evals = S[SS_ST_EVALS], st_cand = S[SS_ST_CAND], st_chain = S[SS_ST_CHAIN];
+  int st_skipped = S[SS_ST_SKIPPED], st_items = S[SS_ST_ITEMS];
   int err = 0;
 
 #if TSG_STAMP
@@ -505,6 +508,7 @@ __global__ __launch_bounds__(256) void frontier_kernel(EngineDev D, int superste
   CKPT(0);
   STAMP_ADD(7, 1);
   bool emitted = false;
+  int pops_here = 0;
   while (!emitted && !err) {
     if (phase == PH_IDLE) {
       if (gen >= TSG_GEN_MAX) {  // table generation space exhausted for this slot: stop refilling it
@@ -570,14 +574,24 @@ __global__ __launch_bounds__(256) void frontier_kernel(EngineDev D, int superste
       it[IT_NCAND] = 0;
       it[IT_DES] = des;
       it[IT_LP] = 0;
-      S[SS_ST_ITEMS] += 1;
+      st_items += 1;
       if (warm_k >= plen - 1) phase = PH_SEARCH;
       emitted = true;
       break;
     }
     // ---- PH_SEARCH: pop until a node can be expanded (search.py:279-300)
     int fin_status = -1, fin_parent = -1, fin_rid = -1, fin_tcode = 0, fin_depth = 0;
+    bool yielded = false;
     while (heap_n > 0 && step < max_step) {
+      // The launch lasts as long as its slowest search, and the number of pops a search needs before it
+      // finds a node worth expanding has a long tail (stale duplicates, expansions that cannot push
+      // anything).  After max_pops pops the search yields: it emits no work item and carries on in the next
+      // superstep.  The operations of a search and their order do not change, only the superstep they land in.
+      if (D.e.max_pops > 0 && pops_here >= D.e.max_pops) {
+        yielded = true;
+        break;
+      }
+      ++pops_here;
       CKPT(6);
       const HeapEnt top = heap_pop(heap, heap_n, nodes);
       CKPT(1);
@@ -647,7 +661,7 @@ __global__ __launch_bounds__(256) void frontier_kernel(EngineDev D, int superste
         }
         if (futile) {
           nd[ND_EXP] = ND_CLOSED_NOSLOT;
-          S[SS_ST_SKIPPED] += 1;
+          st_skipped += 1;
           CKPT(9);
           continue;
         }
@@ -673,14 +687,14 @@ __global__ __launch_bounds__(256) void frontier_kernel(EngineDev D, int superste
       S[SS_CUR_LP] = nd[ND_LP];
       S[SS_CUR_DEPTH] = depth;
       if (C > 1) {  // per-slot statistics (summed on the host; no same-address atomics on the hot path)
-        S[SS_ST_EVALS] += 1;
-        S[SS_ST_CAND] += C;
-        S[SS_ST_CHAIN] += depth;
+        st_evals += 1;
+        st_cand += C;
+        st_chain += depth;
       }
       int32_t* it = my_item;
       it[IT_SLOT] = b;
       it[IT_EXP] = e;
-      S[SS_ST_ITEMS] += 1;
+      st_items += 1;
       it[IT_PARENT] = parent;
       it[IT_RID] = rid;
       it[IT_TCODE] = tcode;
@@ -693,6 +707,10 @@ __global__ __launch_bounds__(256) void frontier_kernel(EngineDev D, int superste
       break;
     }
     if (emitted || err) break;
+    if (yielded) {
+      my_item[IT_SLOT] = -1;
+      break;
+    }
     CKPT(10);
     // ---- the search is over (search.py:421-424): destination popped, queue empty, or budget spent
     if (fin_status < 0) {
@@ -778,6 +796,11 @@ __global__ __launch_bounds__(256) void frontier_kernel(EngineDev D, int superste
   S[SS_BEST_TCODE] = best_tcode;
   S[SS_HAVE_BEST] = have_best;
   S[SS_NPOP] = npop;
+  S[SS_ST_EVALS] = st_evals;
+  S[SS_ST_CAND] = st_cand;
+  S[SS_ST_CHAIN] = st_chain;
+  S[SS_ST_SKIPPED] = st_skipped;
+  S[SS_ST_ITEMS] = st_items;
 }
 
 // =====================================================================================
@@ -807,6 +830,7 @@ static int check_engine(const tsg_model* m, const tsg_graph* g, const tsg_od_bat
     if (!g->geo && !g->dist_table) return TSG_E_INVALID;
     if (e->up_levels != TSG_UP_LEVELS) return TSG_E_INVALID;
     if (e->state_format != 0 && e->state_format != 1) return TSG_E_INVALID;
+    if (e->max_pops < 0) return TSG_E_INVALID;
     if (e->state_format == 1) {
       if (!m->whh0_s) return TSG_E_INVALID;
       for (int l = 1; l < m->n_layers; ++l)

@@ -327,7 +327,7 @@ class AStarEngine(object):
     busy with its LSTM step.  Workspaces are disjoint slices of the same tensors."""
 
     def __init__(self, tables, graph, slots, max_step, max_prefix=1, lmax=256, streams=1, prune=True, use_graph=True,
-                 state_format=1):
+                 state_format=1, max_pops=None):
         self.tables, self.graph = tables, graph
         dev = self.device = tables.device
         n = graph.num_roads
@@ -337,6 +337,9 @@ class AStarEngine(object):
         self.slots = B = self.sub_slots * streams
         self.max_step, self.max_prefix, self.lmax = int(max_step), int(max_prefix), int(lmax)
         self.exp_cap = self.max_prefix + self.max_step
+        if max_pops is None:
+            max_pops = int(os.environ.get('TSG_MAX_POPS', '4'))
+        self.max_pops = int(max_pops)
         self.node_cap = int(min(n, 1 + self.max_step * graph.max_degree)) + 1
         self.heap_cap = 1 + self.max_step * graph.max_degree
         if self.node_cap >= (1 << 20):
@@ -373,6 +376,7 @@ class AStarEngine(object):
             e.up_levels = self.up_levels
             e.prune_spread = self.prune_spread
             e.state_format = int(state_format)
+            e.max_pops = self.max_pops
             e.counters = self.counters[k].data_ptr()
             e.counters_bytes = 64
             e.shared_counters = self.counters[streams].data_ptr()
@@ -470,7 +474,10 @@ class AStarEngine(object):
                 streams[k].wait_stream(main)
                 _lib.check(L.tsg_engine_reset(C.byref(self.c_engines[k]), C.byref(g), handles[k]), 'tsg_engine_reset')
             # every superstep each unfinished slot advances by >= 1 expansion / prefix element / finished OD
-            bound = (math.ceil(n_od / self.slots) + 1) * (self.max_step + self.max_prefix + 2) + 8
+            per_search = self.max_step + self.max_prefix + 2
+            if self.max_pops > 0:       # yields: at most heap_cap pops per search, max_pops of them per superstep
+                per_search += self.heap_cap // self.max_pops + 1
+            bound = (math.ceil(n_od / self.slots) + 1) * per_search + 8
             while True:
                 if profile_every and chunk_i % profile_every == 0:
                     # sampled chunk: drain every stream, then time each sub-engine's kernels on their own
