@@ -80,6 +80,32 @@ def build_model(net, device):
     return model, cfg
 
 
+def gat_encoder_timing(model, net, cfg, reps=5):
+    """One-off kernel group (1): the GAT road-graph encoder.  HIP-event time of the whole tsg_gat_forward
+    (projection GEMM, skip GEMM, node scores, edge max, aggregation) on the launch stream, against its
+    algorithmic HBM bytes: 4N*FIN + 4N*NH*F + E(4NH*F + 8NH + 8) + 4N*F."""
+    import torch
+    fh = model.function_h
+    x = fh.input_features()
+    apt = fh.Apt.to(x.device)
+    fh.gat_encoder((x, apt))
+    torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    ev[0].record()
+    for _ in range(reps):
+        fh.gat_encoder((x, apt))
+    ev[1].record()
+    torch.cuda.synchronize()
+    ms = ev[0].elapsed_time(ev[1]) / reps
+    n, fin = x.shape
+    nh, f = cfg['function_h']['num_of_heads'], cfg['function_h']['embed_dim']
+    e = int(apt.shape[1])
+    byts = 4.0 * n * fin + 4.0 * n * nh * f + e * (4.0 * nh * f + 8 * nh + 8) + 4.0 * n * f
+    return {'ms': ms, 'nodes': int(n), 'edges': e, 'algorithmic_bytes': byts, 'bound': 'hbm',
+            'achieved': byts / (ms * 1e-3) / 1e9, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+            'frac': byts / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS}
+
+
 def cpu_baseline(net, model, cfg, od, budget_s, max_step):
     """The CPU oracle (port of search.py:240-424 + generator_v4.py:56-72) on the first ODs of the workload."""
     import torch
@@ -230,6 +256,7 @@ def main():
             roofline = {'kernel': dom, 'bound': d['bound'], 'achieved': d['achieved'], 'peak': d['peak'],
                         'unit': d['unit'], 'frac': d['frac'], 'traffic': None,
                         'avg_launch_ms': d['avg_ms'], 'rows_per_launch': rows_per_launch}
+        gat = gat_encoder_timing(model, net, cfg)
         cpu = None
         if world == 1 and args.cpu_seconds > 0:
             cpu = cpu_baseline(net, model, cfg, od, args.cpu_seconds, args.max_step)
@@ -244,7 +271,7 @@ def main():
             'reached_frac': float((status & 0xff == 1).mean()), 'fallback_frac': float((status & 0xff == 2).mean()),
             'avg_prefix_len_scored': avg_L, 'avg_candidates_scored': avg_C,
             'supersteps': int(sum(s['supersteps'] for s in stats)),
-            'roofline': roofline, 'kernels': kern, 'cpu_baseline': cpu,
+            'roofline': roofline, 'kernels': kern, 'gat_encoder': gat, 'cpu_baseline': cpu,
         }
         print(json.dumps(out))
     if world > 1:

@@ -85,6 +85,11 @@ typedef struct tsg_gat_desc {
   float* gmax;           /* workspace [1]: global max edge score (gat.py:221) */
   float* out;            /* [N][F] or [N][NH*F] */
   size_t proj_bytes, s_bytes, out_bytes;
+  /* skip connection (gat.py:93-102) as a dense product; unused (may be NULL) when skip_identity */
+  float* skip;           /* workspace, same shape as out: x . Ws^T + bias, with Ws averaged over heads when
+                            concat == 0 (the head mean of gat.py:109 commutes with the skip projection) */
+  float* w_skip_mean;    /* workspace [FIN][F], concat == 0 only */
+  size_t skip_bytes, w_skip_mean_bytes;
 } tsg_gat_desc;
 
 int tsg_gat_forward(const tsg_gat_desc* d, void* stream);

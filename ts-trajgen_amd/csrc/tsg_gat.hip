@@ -63,66 +63,130 @@ __global__ __launch_bounds__(256) void gat_edge_max_kernel(const int32_t* __rest
 }
 
 #define GAT_MAXJ 8  // fout <= 512
-// one block per target node; wave h = head h (blockDim = 64 * heads)
-__global__ void gat_aggregate_kernel(tsg_gat_desc d) {
-  extern __shared__ float lds[];  // [heads][fout] head outputs, then [fin] x row
-  const int n = blockIdx.x;
-  const int h = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int F = d.fout, NH = d.heads, FIN = d.fin;
-  float* head_out = lds;
-  float* xrow = lds + (size_t)NH * F;
-  for (int k = threadIdx.x; k < FIN; k += blockDim.x) xrow[k] = d.x[(size_t)n * FIN + k];
+
+// mean over heads of the skip projection (concat == 0): mean_h(agg_h + x.Ws_h) = mean_h(agg_h) + x.mean_h(Ws_h),
+// so the skip term is one [FIN][F] product instead of NH of them (gat.py:101,109)
+__global__ __launch_bounds__(256) void gat_skip_mean_kernel(const float* __restrict__ w_skip_t, float* __restrict__ w_mean,
+                                                            int fin, int heads, int fout) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= fin * fout) return;
+  const int k = i / fout, f = i % fout;
+  float s = 0.0f;
+  for (int h = 0; h < heads; ++h) s += w_skip_t[(size_t)k * heads * fout + (size_t)h * fout + f];
+  w_mean[i] = s / (float)heads;
+}
+
+// One wave per target node.  Per head: the incoming edges' attention weights are computed one edge per lane
+// (segmented softmax over the node's CSR row, gat.py:225-230,246), then the source rows proj[src][h][:]
+// (F contiguous floats each) are gathered four at a time, the whole wave reading one row coalesced, and
+// accumulated in COO order (mul, then add: gat.py:188,263).  Heads are averaged in registers; the skip
+// term (already a dense product, with the bias folded in) and ELU close the row: no LDS, no second pass.
+// VEC4: F is a multiple of 256 and lane l owns floats 4l..4l+3 of every 256-float segment (dwordx4 loads).
+template <bool VEC4>
+__global__ __launch_bounds__(256) void gat_aggregate_kernel(tsg_gat_desc d) {
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (n >= d.n_nodes) return;
+  const int F = d.fout, NH = d.heads;
   const int e0 = d.in_ptr[n], e1 = d.in_ptr[n + 1];
   const float gmax = *d.gmax;
-  const float st = d.s_trg[(size_t)n * NH + h];
-  // segmented softmax denominator over the incoming edges of n (gat.py:225,246)
-  float denom = 0.0f;
-  for (int e = e0; e < e1; ++e) {
-    const int s = d.in_src[e];
-    denom += expf(leaky02(d.s_src[(size_t)s * NH + h] + st) - gmax);
-  }
-  const float dinv_base = denom + 1e-16f;  // gat.py:230
-  float acc[GAT_MAXJ];
+  const int nv = VEC4 ? F / 64 : (F + 63) / 64;  // floats per lane
+  auto col = [&](int j) { return VEC4 ? (j >> 2) * 256 + 4 * lane + (j & 3) : lane + 64 * j; };
+  float mean_acc[GAT_MAXJ];
 #pragma unroll
-  for (int j = 0; j < GAT_MAXJ; ++j) acc[j] = 0.0f;
-  for (int e = e0; e < e1; ++e) {
-    const int s = d.in_src[e];
-    const float att = expf(leaky02(d.s_src[(size_t)s * NH + h] + st) - gmax) / dinv_base;
-    const float* p = d.proj + ((size_t)s * NH + h) * F;
+  for (int j = 0; j < GAT_MAXJ; ++j) mean_acc[j] = 0.0f;
+  const int outw = d.concat ? NH * F : F;
+  for (int h = 0; h < NH; ++h) {
+    const float st = d.s_trg[(size_t)n * NH + h];
+    // segmented softmax denominator over the incoming edges of n, summed in COO order
+    float denom = 0.0f;
+    for (int c0 = e0; c0 < e1; c0 += 64) {
+      const int cnt = e1 - c0 < 64 ? e1 - c0 : 64;
+      float ex = 0.0f;
+      if (lane < cnt) ex = expf(leaky02(d.s_src[(size_t)d.in_src[c0 + lane] * NH + h] + st) - gmax);
+      for (int i = 0; i < cnt; ++i) denom += __shfl(ex, i, TSG_WAVE);
+    }
+    const float dinv_base = denom + 1e-16f;  // gat.py:230
+    float acc[GAT_MAXJ];
+#pragma unroll
+    for (int j = 0; j < GAT_MAXJ; ++j) acc[j] = 0.0f;
+    for (int c0 = e0; c0 < e1; c0 += 64) {
+      const int cnt = e1 - c0 < 64 ? e1 - c0 : 64;
+      int src = 0;
+      float att = 0.0f;
+      if (lane < cnt) {
+        src = d.in_src[c0 + lane];
+        att = expf(leaky02(d.s_src[(size_t)src * NH + h] + st) - gmax) / dinv_base;
+      }
+      for (int i0 = 0; i0 < cnt; i0 += 4) {
+        float p[4][GAT_MAXJ];
+        float a[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {  // four source rows in flight
+          const int i = i0 + u < cnt ? i0 + u : cnt - 1;
+          const int s = __shfl(src, i, TSG_WAVE);
+          a[u] = __shfl(att, i, TSG_WAVE);
+          const float* row = d.proj + ((size_t)s * NH + h) * F;
+          if (VEC4) {
+#pragma unroll
+            for (int q = 0; q < GAT_MAXJ / 4; ++q) {
+              if (q * 256 < F) {
+                const float4 v = *reinterpret_cast<const float4*>(row + q * 256 + 4 * lane);
+                p[u][4 * q] = v.x;
+                p[u][4 * q + 1] = v.y;
+                p[u][4 * q + 2] = v.z;
+                p[u][4 * q + 3] = v.w;
+              }
+            }
+          } else {
+#pragma unroll
+            for (int j = 0; j < GAT_MAXJ; ++j) {
+              const int f = lane + 64 * j;
+              p[u][j] = f < F ? row[f] : 0.0f;
+            }
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (i0 + u < cnt) {
+#pragma unroll
+            for (int j = 0; j < GAT_MAXJ; ++j)
+              if (j < nv) acc[j] = __fadd_rn(acc[j], __fmul_rn(p[u][j], a[u]));  // mul then add, no fma
+          }
+        }
+      }
+    }
+    if (d.concat) {
+#pragma unroll
+      for (int j = 0; j < GAT_MAXJ; ++j) {
+        const int f = col(j);
+        if (j < nv && f < F) {
+          const size_t o = (size_t)n * outw + (size_t)h * F + f;
+          float v = acc[j];
+          if (d.skip_identity)
+            v += d.x[(size_t)n * d.fin + f] + (d.bias ? d.bias[h * F + f] : 0.0f);  // gat.py:94-97
+          else
+            v += d.skip[o];  // x . Ws^T + bias
+          d.out[o] = v > 0.0f ? v : expm1f(v);  // gat.py:114 ELU
+        }
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < GAT_MAXJ; ++j) mean_acc[j] += acc[j];
+    }
+  }
+  if (!d.concat) {
 #pragma unroll
     for (int j = 0; j < GAT_MAXJ; ++j) {
-      const int f = lane + 64 * j;
-      if (f < F) acc[j] = __fadd_rn(acc[j], __fmul_rn(p[f], att));  // gat.py:188,263 (mul then add, no fma)
-    }
-  }
-  __syncthreads();  // xrow ready
-#pragma unroll
-  for (int j = 0; j < GAT_MAXJ; ++j) {
-    const int f = lane + 64 * j;
-    if (f < F) {
-      float sk;
-      if (d.skip_identity) {
-        sk = xrow[f];  // gat.py:94-97
-      } else {
-        sk = 0.0f;    // gat.py:101 skip_proj
-        const float* w = d.w_skip_t + (size_t)h * F + f;
-        for (int k = 0; k < FIN; ++k) sk += xrow[k] * w[(size_t)k * NH * F];
+      const int f = col(j);
+      if (j < nv && f < F) {
+        float v = mean_acc[j] / (float)NH;  // gat.py:109
+        if (d.skip_identity)
+          v += d.x[(size_t)n * d.fin + f] + (d.bias ? d.bias[f] : 0.0f);
+        else
+          v += d.skip[(size_t)n * F + f];  // x . mean_h(Ws_h)^T + bias (gat.py:101,109,112)
+        d.out[(size_t)n * F + f] = v > 0.0f ? v : expm1f(v);
       }
-      head_out[h * F + f] = acc[j] + sk;
-    }
-  }
-  __syncthreads();
-  if (d.concat) {
-    for (int i = threadIdx.x; i < NH * F; i += blockDim.x) {
-      float v = head_out[i] + (d.bias ? d.bias[i] : 0.0f);
-      d.out[(size_t)n * NH * F + i] = v > 0.0f ? v : expm1f(v);
-    }
-  } else {
-    for (int f = threadIdx.x; f < F; f += blockDim.x) {
-      float sum = 0.0f;
-      for (int hh = 0; hh < NH; ++hh) sum += head_out[hh * F + f];
-      float v = sum / (float)NH + (d.bias ? d.bias[f] : 0.0f);  // gat.py:109,112
-      d.out[(size_t)n * F + f] = v > 0.0f ? v : expm1f(v);        // gat.py:114 ELU
     }
   }
 }
@@ -134,15 +198,33 @@ extern "C" int tsg_gat_forward(const tsg_gat_desc* d, void* stream) {
   if (!d->x || !d->w_proj_t || !d->a_src || !d->a_trg || !d->in_ptr || !d->in_src || !d->proj || !d->s_src ||
       !d->s_trg || !d->gmax || !d->out)
     return TSG_E_INVALID;
-  if (!d->skip_identity && !d->w_skip_t) return TSG_E_INVALID;
   if (d->skip_identity && d->fin != d->fout) return TSG_E_INVALID;
   const size_t N = (size_t)d->n_nodes, HF = (size_t)d->heads * d->fout;
+  const size_t outw = d->concat ? HF : (size_t)d->fout;
   if (d->proj_bytes < N * HF * 4 || d->s_bytes < N * d->heads * 4) return TSG_E_TOO_SMALL;
-  if (d->out_bytes < N * (d->concat ? HF : (size_t)d->fout) * 4) return TSG_E_TOO_SMALL;
+  if (d->out_bytes < N * outw * 4) return TSG_E_TOO_SMALL;
+  if (!d->skip_identity) {
+    if (!d->w_skip_t || !d->skip) return TSG_E_INVALID;
+    if (d->skip_bytes < N * outw * 4) return TSG_E_TOO_SMALL;
+    if (!d->concat && (!d->w_skip_mean || d->w_skip_mean_bytes < (size_t)d->fin * d->fout * 4)) return TSG_E_TOO_SMALL;
+  }
   hipStream_t s = (hipStream_t)stream;
   int rc = tsg_gemm_f32(d->x, d->fin, d->w_proj_t, (int)HF, nullptr, d->proj, (int)HF, d->n_nodes, (int)HF, d->fin,
                         stream);
   if (rc) return rc;
+  if (!d->skip_identity) {  // the skip connection as a dense product on the matrix cores, bias folded in
+    if (d->concat) {
+      rc = tsg_gemm_f32(d->x, d->fin, d->w_skip_t, (int)HF, d->bias, d->skip, (int)HF, d->n_nodes, (int)HF, d->fin,
+                        stream);
+    } else {
+      hipLaunchKernelGGL(gat_skip_mean_kernel, dim3(tsg_cdiv((long)d->fin * d->fout, 256)), dim3(256), 0, s,
+                         d->w_skip_t, d->w_skip_mean, d->fin, d->heads, d->fout);
+      TSG_LAUNCH_CHECK();
+      rc = tsg_gemm_f32(d->x, d->fin, d->w_skip_mean, d->fout, d->bias, d->skip, d->fout, d->n_nodes, d->fout,
+                        d->fin, stream);
+    }
+    if (rc) return rc;
+  }
   hipLaunchKernelGGL(gat_node_scores_kernel, dim3(tsg_cdiv((long)N * d->heads, 4)), dim3(256), 0, s, d->proj, d->a_src,
                      d->a_trg, d->s_src, d->s_trg, d->n_nodes, d->heads, d->fout);
   TSG_LAUNCH_CHECK();
@@ -152,9 +234,11 @@ extern "C" int tsg_gat_forward(const tsg_gat_desc* d, void* stream) {
   hipLaunchKernelGGL(gat_edge_max_kernel, dim3(mgrid), dim3(256), 0, s, d->in_ptr, d->in_src, d->s_src, d->s_trg,
                      d->gmax, d->n_nodes, d->heads);
   TSG_LAUNCH_CHECK();
-  const size_t lds = (HF + (size_t)d->fin) * 4;
-  if (lds > 64 * 1024) return TSG_E_LIMIT;
-  hipLaunchKernelGGL(gat_aggregate_kernel, dim3(d->n_nodes), dim3(64 * d->heads), lds, s, *d);
+  const dim3 agrid(tsg_cdiv(d->n_nodes, 4));
+  if (d->fout % 256 == 0)
+    hipLaunchKernelGGL(gat_aggregate_kernel<true>, agrid, dim3(256), 0, s, *d);
+  else
+    hipLaunchKernelGGL(gat_aggregate_kernel<false>, agrid, dim3(256), 0, s, *d);
   TSG_LAUNCH_CHECK();
   return 0;
 }

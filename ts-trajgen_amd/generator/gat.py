@@ -99,6 +99,12 @@ class GATLayerImp3(nn.Module):
         d.in_ptr, d.in_src = _lib.ptr(in_ptr), _lib.ptr(in_src)
         d.proj, d.s_src, d.s_trg, d.gmax, d.out = (_lib.ptr(proj), _lib.ptr(s_src), _lib.ptr(s_trg),
                                                     _lib.ptr(gmax), _lib.ptr(out))
+        if fin != fo:       # skip projection workspaces (x . Ws^T + bias on the matrix cores)
+            skip = torch.empty_like(out)
+            d.skip, d.skip_bytes = _lib.ptr(skip), skip.numel() * 4
+            if not self.concat:
+                w_mean = torch.empty((fin, fo), dtype=torch.float32, device=dev)
+                d.w_skip_mean, d.w_skip_mean_bytes = _lib.ptr(w_mean), w_mean.numel() * 4
         d.proj_bytes = proj.numel() * 4
         d.s_bytes = s_src.numel() * 4
         d.out_bytes = out.numel() * 4
