@@ -80,6 +80,27 @@ def build_model(net, device):
     return model, cfg
 
 
+def pmc_traffic(kernel, lstm):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/pmc_traffic.json, written by
+    tools/gpu_profile.sh + tools/pmc_summary.py: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this
+    same bench at 8192 OD pairs, corrected as MI355X_MICROARCH.md prescribes).  Counters cannot be read from
+    inside the timed run, so this is the figure of that pass, not of this run; None when absent."""
+    path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+    if not os.path.exists(path):
+        return None, None
+    with open(path) as f:
+        js = json.load(f)
+    names = {'frontier_kernel': 'frontier_kernel', 'score_frontier_kernel': 'score_frontier_kernel<4, true>',
+             'lstm_layer_kernel[l0]': 'lstm_layer_split_kernel<true>' if lstm == 'split' else 'lstm_layer_kernel<true>',
+             'lstm_layer_kernel[l1]': 'lstm_layer_split_kernel<false>' if lstm == 'split' else 'lstm_layer_kernel<false>'}
+    e = js.get(names.get(kernel, kernel))
+    if not e:
+        return None, None
+    if 'hbm_bytes_corrected' in e:
+        return e['hbm_bytes_corrected'], 'profiles/pmc_traffic.json: 2*FETCH_SIZE + WRITE_SIZE per launch (gfx950 correction)'
+    return e['hbm_bytes_raw'], 'profiles/pmc_traffic.json: FETCH_SIZE + WRITE_SIZE per launch, raw (narrow accesses: uncalibrated)'
+
+
 def gat_encoder_timing(model, net, cfg, reps=5):
     """One-off kernel group (1): the GAT road-graph encoder.  HIP-event time of the whole tsg_gat_forward
     (projection GEMM, skip GEMM, node scores, edge max, aggregation) on the launch stream, against its
@@ -253,8 +274,9 @@ def main():
         roofline = None
         if dom:
             d = kern[dom]
+            traffic, traffic_src = pmc_traffic(dom, args.lstm)
             roofline = {'kernel': dom, 'bound': d['bound'], 'achieved': d['achieved'], 'peak': d['peak'],
-                        'unit': d['unit'], 'frac': d['frac'], 'traffic': None,
+                        'unit': d['unit'], 'frac': d['frac'], 'traffic': traffic, 'traffic_source': traffic_src,
                         'avg_launch_ms': d['avg_ms'], 'rows_per_launch': rows_per_launch}
         gat = gat_encoder_timing(model, net, cfg)
         cpu = None
