@@ -185,7 +185,7 @@ def main():
     if slots <= 0:
         from ts_trajgen_amd.search import _auto_slots
         slots = _auto_slots(tables, searcher.graph(), args.max_step, 1, args.ods, torch.device(device),
-                            budget_frac=0.7, cap=8192)
+                            budget_frac=0.93, cap=12288)
 
     def one_step(o, profile_every=0):
         res = searcher.generate(model, o['start'], o['start_time'], o['des'], o['default_len'],

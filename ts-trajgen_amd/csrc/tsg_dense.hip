@@ -338,7 +338,7 @@ __device__ __forceinline__ unsigned tsg_split_word(float x) {
 }
 
 template <bool LAYER0>
-__global__ __launch_bounds__(256, 2) void lstm_layer_split_kernel(LstmArgs a) {
+__global__ __launch_bounds__(256, 3) void lstm_layer_split_kernel(LstmArgs a) {
   __shared__ TileB16 tb[2];
   __shared__ long long s_prev[BM];
   __shared__ long long s_out[BM];
