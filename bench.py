@@ -48,7 +48,9 @@ def parse():
     ap.add_argument('--max-step', type=int, default=5000)
     ap.add_argument('--slots', type=int, default=0, help='searches in flight per GPU (0 = auto)')
     ap.add_argument('--lmax', type=int, default=256)
-    ap.add_argument('--streams', type=int, default=1, help='sub-engines (HIP streams) per GPU sharing the OD queue')
+    ap.add_argument('--oversub', type=float, default=2.2,
+                    help='searches in flight per worst-case reservation of the state-page pool (1 = reserve the worst case)')
+    ap.add_argument('--ramp', type=int, default=1500, help='supersteps over which the first searches are started')
     ap.add_argument('--profile-every', type=int, default=8, help='event-bracket every k-th chunk of supersteps')
     ap.add_argument('--lstm', default='split', choices=['split', 'fp32'],
                     help='recurrent matmul: split-f16 three-pass matrix-core form (fp32-grade products) or plain fp32 MFMA')
@@ -181,16 +183,27 @@ def main():
     searcher = Searcher(device, net.adjacent_list, net.rid_gps, net.road_length, net.road_time_distribution)
     searcher.state_format = 1 if args.lstm == 'split' else 0
     tables = model.tables()
+    # searches in flight and the state-page pool they share: HBM holds `slots` fixed workspaces plus a pool that
+    # would cover the worst case of slots / oversub searches (a search holds only the pages it has filled)
+    from ts_trajgen_amd.engine import AStarEngine
+    fixed = AStarEngine.fixed_bytes_per_slot(searcher.graph(), args.max_step, 1)
+    page = AStarEngine.bytes_per_page(tables)
+    pps = (1 + args.max_step + 63) // 64
+    free_b, _total = torch.cuda.mem_get_info(torch.device(device))
+    budget = int(free_b * 0.93) - (2 * args.lmax + 8) * 4 * args.ods
     slots = args.slots
     if slots <= 0:
-        from ts_trajgen_amd.search import _auto_slots
-        slots = _auto_slots(tables, searcher.graph(), args.max_step, 1, args.ods, torch.device(device),
-                            budget_frac=0.93, cap=12288)
+        slots = int(budget // (fixed + pps * page / args.oversub))
+        slots = min(slots, 32768, args.ods)
+        # LSTM grid: 8 workgroups per 128 searches, 768 resident at a time -> whole waves of workgroups at 12 288
+        slots = slots // 12288 * 12288 if slots >= 12288 else max(128, slots // 1024 * 1024 if slots >= 1024 else slots // 128 * 128)
+    pool_pages = min(slots * pps, int((budget - slots * fixed) // page))
+    ramp = args.ramp if pool_pages < slots * pps else 0
 
     def one_step(o, profile_every=0):
         res = searcher.generate(model, o['start'], o['start_time'], o['des'], o['default_len'],
                                 max_step=args.max_step, slots=slots, lmax=args.lmax, return_device=True,
-                                profile_every=profile_every, streams=args.streams)
+                                profile_every=profile_every, pool_pages=pool_pages, ramp_steps=ramp)
         if world > 1:   # the single exchange step of the path: collect the padded trajectories (RCCL over xGMI)
             packed = torch.cat([res['rid'], res['time'], res['len'].unsqueeze(1), res['status'].unsqueeze(1)], dim=1)
             gathered = torch.empty((world * packed.shape[0], packed.shape[1]), dtype=packed.dtype,
@@ -288,11 +301,14 @@ def main():
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': '%s, %d OD pairs per GPU, BJ model dims (hidden 256, 2-layer LSTM, GAT 5x256), '
                                    'random-init weights, max_step %d' % (net_name, args.ods, args.max_step),
-                       'od_pairs_per_gpu': args.ods, 'slots_in_flight': slots, 'streams': args.streams, 'lstm': args.lstm, 'parallelism': 'od-shard x%d' % world},
+                       'od_pairs_per_gpu': args.ods, 'slots_in_flight': slots, 'state_pool_pages': pool_pages,
+                       'state_pool_gb': pool_pages * page / 1e9, 'lstm': args.lstm, 'parallelism': 'od-shard x%d' % world},
             'expansions_per_s': exp_all / dt, 'expansions_per_od': exp_all / n_done,
             'reached_frac': float((status & 0xff == 1).mean()), 'fallback_frac': float((status & 0xff == 2).mean()),
             'avg_prefix_len_scored': avg_L, 'avg_candidates_scored': avg_C,
             'supersteps': int(sum(s['supersteps'] for s in stats)),
+            'page_waits': int(sum(s['page_waits'] for s in stats)), 'restarts': int(sum(s['restarts'] for s in stats)),
+            'min_free_pages': int(min(s['min_free_pages'] for s in stats)),
             'roofline': roofline, 'kernels': kern, 'gat_encoder': gat, 'cpu_baseline': cpu,
         }
         print(json.dumps(out))

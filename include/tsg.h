@@ -231,7 +231,8 @@ typedef struct tsg_engine {
   uint32_t* table;      size_t table_bytes;       /* [B][n_roads] rid -> (generation<<20 | node+1), zeroed by caller */
   int32_t* nodes;       size_t nodes_bytes;       /* [B][node_cap][8] int32 */
   int32_t* exp_meta;    size_t exp_meta_bytes;    /* [B][exp_cap][4] {parent, rid, tcode, depth} */
-  int32_t* exp_up;      size_t exp_up_bytes;      /* [B][exp_cap][64]: exp_up[e][i] = the (i+1)-th ancestor slot of e, -1 = none */
+  int32_t* exp_up;      size_t exp_up_bytes;      /* [n_pages*64][64]: exp_up[row][i] = state row of the (i+1)-th ancestor
+                                                     of the node in state row `row`, -1 = none */
   int32_t up_levels;    float prune_spread;       /* |1-w1| + |w1| of the model (0 = only the all-closed rule): bound used to
                                                      skip expansions that cannot push anything, see tsg_search.hip */
   /* up_levels must be TSG_UP_LEVELS */
@@ -244,24 +245,42 @@ typedef struct tsg_engine {
                                                      superstep without finding a node to expand yields until the next
                                                      superstep (0 = no limit); bounds the launch time by the typical,
                                                      not the worst, search; results do not depend on it */
-  float* h[TSG_MAX_LAYERS];                       /* [B*exp_cap][Hp] per layer */
+  float* h[TSG_MAX_LAYERS];                       /* [n_pages*64][Hp] per layer */
   float* c[TSG_MAX_LAYERS];
   size_t state_bytes;                             /* bytes of EACH h[l] / c[l] */
-  int32_t* items;       size_t items_bytes;       /* [B][8] work item of each search for the current superstep
+  /* State pages.  The recurrent state, and the ancestor list, of an expanded node live in a state ROW; rows
+   * come in pages of 64 from a pool shared by all searches (a search that ends after 300 expansions holds 5
+   * pages, not the worst case of exp_cap rows), so many more searches fit in HBM than exp_cap * slots rows
+   * would allow.  n_pages == slots * pages_per_slot reserves the worst case (then nothing below can trigger).
+   * With a smaller pool: new searches are admitted only out of the surplus above admit_reserve free pages; a
+   * search that finds no free page waits (emits no work item) until pages are returned; if every search that
+   * wants to run is waiting, the youngest ones (fewest pages) give their pages back and their OD pair is
+   * queued again (`retry`), restarting from scratch later: results do not depend on any of this. */
+  int32_t n_pages;        int32_t pages_per_slot; /* pool size; ceil(exp_cap / 64) */
+  int32_t admit_reserve;  int32_t ramp_steps;     /* slot b starts its first search at superstep b * ramp_steps / slots:
+                                                     spreads the ages of the first generation of searches */
+  int32_t* slot_pages;  size_t slot_pages_bytes;  /* [B][pages_per_slot] page ids of each search, in order */
+  int32_t* page_ring;   size_t page_ring_bytes;   /* [n_pages] free ring */
+  int32_t* retry;       size_t retry_bytes;       /* [>= n_od + B] ring of OD indices waiting to restart */
+  int32_t* page_flags;  size_t page_flags_bytes;  /* [2][256][32] progress / wait stamps of the superstep, spread over
+                                                     256 cache lines each (gathered by the control step) */
+  int32_t* items;       size_t items_bytes;       /* [B][12] work item of each search for the current superstep
                                                      (word 0 = slot, or -1 when the search emitted none) */
   float* cand_lp;       size_t cand_lp_bytes;     /* [B][max_degree] */
   int32_t* shared_counters;                       /* [16] words 2,3,4,6 below; == counters for a lone engine.  Several
                                                      engines (disjoint workspaces, one HIP stream each) that work on
                                                      the SAME tsg_od_batch share this array: one OD queue */
-  int32_t* counters;    size_t counters_bytes;    /* [16]: 0,1 item counters (ping-pong), 2 next OD, 3 finished ODs,
-                                                     4 total expansions, 5 unused, 6 error flag,
-                                                     7 total work items (LSTM rows).  Per-slot statistics live in
-                                                     slot_state words 27..29: model evaluations, scored candidates,
-                                                     attention chain rows */
+  int32_t* counters;    size_t counters_bytes;    /* [16] state-page control of THIS engine: 0 ring head, 1 ring tail,
+                                                     2 tail snapshot, 3-5 the same for `retry`, 6 waits, 7 restarts,
+                                                     8 restart level, 9-10 unused, 11 superstep,
+                                                     12 fewest free pages seen, 13 admission quota, 14 restart budget.
+                                                     shared_counters: 2 next OD, 3 finished ODs, 4 total expansions,
+                                                     6 error flag.  Per-slot statistics live in slot_state words
+                                                     27..29: model evaluations, scored candidates, attention rows */
 } tsg_engine;
 
-/* Reset slot states, the rid table and `counters` for a new OD batch (enqueues memsets).  The caller zeroes
- * `shared_counters` itself when it is a separate array. */
+/* Reset slot states, the rid table, the page ring and `counters` for a new OD batch (enqueues memsets and one
+ * small kernel).  The caller zeroes `shared_counters` itself when it is a separate array. */
 int tsg_engine_reset(const tsg_engine* e, const tsg_graph* g, void* stream);
 
 /* Enqueue `n_supersteps` supersteps.  `first_superstep` is the index of the first one (parity

@@ -195,3 +195,32 @@ def test_config1_split_recurrence_against_fp32(porto):
     same = sum(int(torch.equal(out[0]['rid'][i], out[1]['rid'][i]) and torch.equal(out[0]['time'][i], out[1]['time'][i]))
                for i in range(512))
     assert same >= 512 - 5, same
+
+
+def test_config1_state_page_pool_under_pressure(porto):
+    """A state-page pool far smaller than the worst case (searches wait for pages, the youngest are sent back and
+    restart) gives bit-identical trajectories, and every OD pair is finished exactly once."""
+    from ts_trajgen_amd.search import Searcher
+    net, model, cfg, od = porto
+    s = Searcher(DEV, net.adjacent_list, net.rid_gps, net.road_length, net.road_time_distribution)
+    sub = slice(0, 640)
+    args = (model, od['start'][sub], od['start_time'][sub], od['des'][sub], od['default_len'][sub])
+    ref = s.generate(*args, max_step=5000, slots=256, lmax=256)
+    assert s.last_stats['page_waits'] == 0 and s.last_stats['restarts'] == 0
+    pps = (1 + 5000 + 63) // 64
+    # 512 searches in flight on a pool that covers the worst case of 48 of them
+    got = s.generate(*args, max_step=5000, slots=512, lmax=256, pool_pages=48 * pps, ramp_steps=500)
+    st = dict(s.last_stats)
+    for k in ('rid', 'time', 'len', 'status', 'steps'):
+        assert torch.equal(ref[k], got[k]), k
+    assert st['min_free_pages'] < 48 * pps // 4, st      # the pool did run low
+    # a pool of barely more than one search: everything serialises behind waits and restarts
+    sub2 = slice(0, 48)
+    args2 = (model, od['start'][sub2], od['start_time'][sub2], od['des'][sub2], od['default_len'][sub2])
+    ref2 = s.generate(*args2, max_step=600, slots=16, lmax=256)
+    pps2 = (1 + 600 + 63) // 64
+    got2 = s.generate(*args2, max_step=600, slots=16, lmax=256, pool_pages=pps2 + 3, admit_reserve=2)
+    st2 = dict(s.last_stats)
+    for k in ('rid', 'time', 'len', 'status', 'steps'):
+        assert torch.equal(ref2[k], got2[k]), k
+    assert st2['page_waits'] > 0 and st2['restarts'] > 0, st2

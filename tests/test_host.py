@@ -40,13 +40,21 @@ def test_library_exports_every_declared_symbol():
     assert lib.tsg_version() == 1
 
 
-def test_struct_sizes_match_header():
-    """ctypes mirrors have the field counts/sizes the header implies (pointer = 8, int32 = 4)."""
+def test_struct_sizes_match_header(tmp_path):
+    """The ctypes mirrors are as large as the C structs of include/tsg.h (compiled here with gcc)."""
+    import subprocess
     from ts_trajgen_amd import _lib
-    assert ctypes.sizeof(_lib.Graph) == 8 + 8 * 8
-    assert ctypes.sizeof(_lib.Model) == 16 + (3 + 8 + 5 + 5) * 8
-    assert ctypes.sizeof(_lib.Engine) == 16 + 5 * 16 + 16 + 8 + 8 + 8 * 8 + 8 + 3 * 16 + 8
-    assert ctypes.sizeof(_lib.Rollout) == 16 + 11 * 8 + 8 * 8 + 8 + 4 * 8
+    names = [('tsg_gat_desc', _lib.GatDesc), ('tsg_model', _lib.Model), ('tsg_lstm_step', _lib.LstmStep),
+             ('tsg_score_batch', _lib.ScoreBatch), ('tsg_graph', _lib.Graph), ('tsg_od_batch', _lib.OdBatch),
+             ('tsg_engine', _lib.Engine), ('tsg_rollout', _lib.Rollout)]
+    src = tmp_path / 'sizes.c'
+    src.write_text('#include <stdio.h>\n#include "tsg.h"\nint main(void) {\n' +
+                   ''.join('  printf("%%zu\\n", sizeof(%s));\n' % n for n, _ in names) + '  return 0;\n}\n')
+    exe = tmp_path / 'sizes'
+    subprocess.check_call(['gcc', '-I', os.path.join(ROOT, 'include'), str(src), '-o', str(exe)])
+    sizes = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    for (n, cls), sz in zip(names, sizes):
+        assert ctypes.sizeof(cls) == sz, n
 
 
 def test_gate_permutation_roundtrip():

@@ -70,6 +70,9 @@ class Engine(C.Structure):
                 ('exp_meta', _p), ('exp_meta_bytes', _sz), ('exp_up', _p), ('exp_up_bytes', _sz),
                 ('up_levels', _i32), ('prune_spread', C.c_float), ('state_format', _i32), ('max_pops', _i32),
                 ('h', _p * TSG_MAX_LAYERS), ('c', _p * TSG_MAX_LAYERS), ('state_bytes', _sz),
+                ('n_pages', _i32), ('pages_per_slot', _i32), ('admit_reserve', _i32), ('ramp_steps', _i32),
+                ('slot_pages', _p), ('slot_pages_bytes', _sz), ('page_ring', _p), ('page_ring_bytes', _sz),
+                ('retry', _p), ('retry_bytes', _sz), ('page_flags', _p), ('page_flags_bytes', _sz),
                 ('items', _p), ('items_bytes', _sz), ('cand_lp', _p), ('cand_lp_bytes', _sz),
                 ('shared_counters', _p), ('counters', _p), ('counters_bytes', _sz)]
 

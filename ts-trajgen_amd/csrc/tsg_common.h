@@ -44,13 +44,23 @@ enum {
   SS_PHASE = 0, SS_OD, SS_STEP, SS_HEAP_N, SS_NODE_N, SS_EXP_N, SS_GEN, SS_WOFF, SS_DES, SS_DEFLEN,
   SS_MAXSTEP, SS_ALLOW, SS_WARM_K, SS_PLEN, SS_CUR_EXP, SS_CUR_RID, SS_CUR_C, SS_CUR_DATE_TIME,
   SS_CUR_LP, SS_BEST_LP, SS_BEST_PARENT, SS_BEST_RID, SS_BEST_TCODE, SS_HAVE_BEST, SS_NPOP, SS_POFF,
-  SS_CUR_DEPTH, SS_ST_EVALS, SS_ST_CAND, SS_ST_CHAIN, SS_CUR_COST, SS_ST_SKIPPED, SS_ST_ITEMS, SS_WORDS = 40
+  SS_CUR_DEPTH, SS_ST_EVALS, SS_ST_CAND, SS_ST_CHAIN, SS_CUR_COST, SS_ST_SKIPPED, SS_ST_ITEMS, SS_PAGES, SS_ST_STALLS,
+  SS_WORDS = 40
 };
 enum { PH_IDLE = 0, PH_WARMUP = 1, PH_SEARCH = 2, PH_EXPANDED = 3, PH_DONE = 4 };
-// counters
+// shared counters (tsg_engine.shared_counters)
 enum { CT_ITEMS0 = 0, CT_ITEMS1 = 1, CT_NEXT_OD = 2, CT_FINISHED = 3, CT_EXPANSIONS = 4, CT_MODEL_EVALS = 5, CT_ERROR = 6, CT_ITEMS_TOTAL = 7 };
-// work item words ([B][8] int32)
-enum { IT_SLOT = 0, IT_EXP, IT_PARENT, IT_RID, IT_TCODE, IT_NCAND, IT_DES, IT_LP, IT_WORDS = 8 };
+// state-page control words (tsg_engine.counters): free ring [head, tail) of page ids, retry ring of aborted OD
+// pairs, admission and deadlock control.  *_SNAP = the tail as it stood when the launch began: a launch consumes
+// only what earlier launches produced.
+enum {
+  PC_HEAD = 0, PC_TAIL, PC_TAIL_SNAP, PC_RHEAD, PC_RTAIL, PC_RTAIL_SNAP, PC_STALLS, PC_ABORTS, PC_ABORT_LEVEL,
+  PC_PROGRESS, PC_STALL_STEP, PC_SUPERSTEP, PC_MIN_FREE, PC_ADMIT_QUOTA, PC_ABORT_BUDGET, PC_WORDS = 16
+};
+// work item words ([B][12] int32); ROW / PROW = state rows (page * 64 + offset) of the node and of its parent
+enum { IT_SLOT = 0, IT_ROW, IT_PROW, IT_RID, IT_TCODE, IT_NCAND, IT_DES, IT_LP, IT_DEPTH, IT_WORDS = 12 };
+#define TSG_PAGE_ROWS 64
+#define TSG_PAGE_SHIFT 6
 // node record words ([B][node_cap][8] int32)
 enum { ND_RID = 0, ND_PARENT, ND_LP, ND_DATE_TIME, ND_EXP, ND_WORDS = 8 };
 enum { ND_OPEN = -1, ND_CLOSED_NOSLOT = -2 };

@@ -117,7 +117,7 @@ struct LstmArgs {
   const int32_t* rid;
   const int32_t* tcode;
   const int32_t* items;  // engine mode when non-null: [n][IT_WORDS]
-  int exp_cap;           // engine mode: state row = slot * exp_cap + exp
+  int exp_cap;           // unused (engine work items carry state rows)
   const float* h_below;
   float* h;
   float* c;
@@ -156,9 +156,8 @@ __global__ __launch_bounds__(256, 2) void lstm_layer_kernel(LstmArgs a) {
       if (a.items) {
         const int32_t* it = a.items + (size_t)m * IT_WORDS;
         if (it[IT_SLOT] >= 0) {  // a search without a work item this superstep leaves its row inert
-          const long long base = (long long)it[IT_SLOT] * a.exp_cap;
-          pv = it[IT_PARENT] >= 0 ? base + it[IT_PARENT] : -1;
-          ov = base + it[IT_EXP];
+          pv = it[IT_PROW];      // state rows (page * 64 + offset), -1 = no parent
+          ov = it[IT_ROW];
           rd = it[IT_RID];
           tc = it[IT_TCODE];
         }
@@ -362,9 +361,8 @@ __global__ __launch_bounds__(256, 3) void lstm_layer_split_kernel(LstmArgs a) {
       if (a.items) {
         const int32_t* it = a.items + (size_t)m * IT_WORDS;
         if (it[IT_SLOT] >= 0) {
-          const long long base = (long long)it[IT_SLOT] * a.exp_cap;
-          pv = it[IT_PARENT] >= 0 ? base + it[IT_PARENT] : -1;
-          ov = base + it[IT_EXP];
+          pv = it[IT_PROW];
+          ov = it[IT_ROW];
           rd = it[IT_RID];
           tc = it[IT_TCODE];
         }

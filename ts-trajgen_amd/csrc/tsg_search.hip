@@ -94,9 +94,78 @@ struct EngineDev {
 // item, so the fp64 Vincenty iteration runs on full wavefronts.  Writes kilometres * 10 as f32
 // (search.py:355-356) into cand_lp[slot][c], where the scoring kernel picks it up and overwrites it with
 // the candidate's log-probability.
+// Once per superstep, by one thread, after the frontier kernel: close the books of the state-page pool.
+//   * ring heads may have overshot their snapshot (a failed take still increments): clamp them;
+//   * what the launch returned becomes available to the next launch (tail snapshots);
+//   * new searches are admitted only out of the surplus above admit_reserve (quota = surplus / 2 searches per
+//     superstep: a new search takes a page at once and more soon), so the running searches keep first call
+//     on the pool; an empty engine admits freely;
+//   * if some search waited for a page and no search made progress, the pool is deadlocked: raise the restart
+//     level (searches holding at most that many pages may give them back and queue again), doubling until
+//     something moves, and hand out a budget of pages to free, so that of several equally young searches
+//     only as many restart as it takes; any progress resets the level.
+__device__ __forceinline__ void engine_control_step(const EngineDev& D, bool progressed, bool waited) {
+  int32_t* pc = D.e.counters;
+  const int ss = pc[PC_SUPERSTEP];
+  const int tsnap = pc[PC_TAIL_SNAP];
+  int head = pc[PC_HEAD];
+  if (head > tsnap) head = tsnap;
+  pc[PC_HEAD] = head;
+  const int tail = pc[PC_TAIL];
+  pc[PC_TAIL_SNAP] = tail;
+  const int rsnap = pc[PC_RTAIL_SNAP];
+  int rhead = pc[PC_RHEAD];
+  if (rhead > rsnap) rhead = rsnap;
+  pc[PC_RHEAD] = rhead;
+  pc[PC_RTAIL_SNAP] = pc[PC_RTAIL];
+  const int free_pages = tail - head;
+  if (free_pages < pc[PC_MIN_FREE]) pc[PC_MIN_FREE] = free_pages;
+  int quota = free_pages >= D.e.n_pages ? D.e.slots : (free_pages - D.e.admit_reserve) / 2;
+  pc[PC_ADMIT_QUOTA] = quota > 0 ? quota : 0;
+  int level = pc[PC_ABORT_LEVEL];
+  int budget = 0;
+  if (waited && !progressed) {
+    level = level > 0 ? (2 * level < D.e.pages_per_slot ? 2 * level : D.e.pages_per_slot) : 1;
+    budget = D.e.admit_reserve / 2 > 1 ? D.e.admit_reserve / 2 : 1;
+  } else if (progressed) {
+    level = 0;
+  }
+  pc[PC_ABORT_LEVEL] = level;
+  pc[PC_ABORT_BUDGET] = budget;
+  pc[PC_SUPERSTEP] = ss + 1;
+}
+
+// "Did any search make progress / wait for a page in this superstep?"  Thousands of searches answer per launch;
+// one flag word would be thousands of stores to one address (which the memory system serialises), so search b
+// stamps word (b % 256) * 32 of its flag plane (256 words, one per 128-byte line) and one workgroup gathers them.
+#define TSG_FLAG_PLANE (256 * 32)
+__device__ __forceinline__ void engine_control_block(const EngineDev& D) {  // all 256 threads of one workgroup
+  const int stamp = D.e.counters[PC_SUPERSTEP] + 1;
+  const int p = D.e.page_flags[threadIdx.x * 32] == stamp;
+  const int w = D.e.page_flags[TSG_FLAG_PLANE + threadIdx.x * 32] == stamp;
+  const int any_p = __syncthreads_or(p), any_w = __syncthreads_or(w);
+  if (threadIdx.x == 0) engine_control_step(D, any_p != 0, any_w != 0);
+}
+
+__global__ __launch_bounds__(256) void engine_control_kernel(EngineDev D) { engine_control_block(D); }
+
+__global__ void engine_init_pages_kernel(tsg_engine e) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < e.n_pages) e.page_ring[i] = i;
+  if (i == 0) {
+    int32_t* pc = e.counters;
+    for (int k = 0; k < PC_WORDS; ++k) pc[k] = 0;
+    pc[PC_TAIL] = e.n_pages;
+    pc[PC_TAIL_SNAP] = e.n_pages;
+    pc[PC_MIN_FREE] = e.n_pages;
+    pc[PC_ADMIT_QUOTA] = e.slots;
+  }
+}
+
 __global__ __launch_bounds__(256) void cand_dis_kernel(EngineDev D, int superstep) {
   const int md = D.g.max_degree;
   const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (blockIdx.x == 0 && D.od.n_od > 0) engine_control_block(D);  // engine run (not the stand-alone scoring entry)
   const int idx = (int)(t / md), c = (int)(t % md);
   if (idx >= D.e.slots) return;
   const int32_t* it = D.e.items + (size_t)idx * IT_WORDS;  // items are indexed by slot
@@ -126,20 +195,19 @@ __global__ __launch_bounds__(256) void score_frontier_kernel(tsg_model m, Engine
   const int32_t* it = D.e.items + (size_t)idx * IT_WORDS;  // items are indexed by slot
   if (it[IT_SLOT] < 0) return;                               // this search emitted nothing (finished batch)
   const int ncand = it[IT_NCAND];
-  const int b = it[IT_SLOT], e = it[IT_EXP];
-  constexpr int LV = TSG_UP_LEVELS;  // = 64 ancestors per slot
-  int32_t* anc = D.e.exp_up + (size_t)b * D.e.exp_cap * LV;
-  const int parent = it[IT_PARENT];
-  // lane i: the (i+1)-th ancestor of e; kept in a register (this wave must not read back its own store)
+  const int b = it[IT_SLOT], e = it[IT_ROW];  // e: the state row of the expanded node
+  constexpr int LV = TSG_UP_LEVELS;  // = 64 ancestors per row
+  int32_t* anc = D.e.exp_up;
+  const int parent = it[IT_PROW];
+  // lane i: the state row of the (i+1)-th ancestor; kept in a register (this wave must not read back its own store)
   int mine = lane == 0 ? parent : (parent >= 0 ? anc[(size_t)parent * LV + lane - 1] : -1);
   anc[(size_t)e * LV + lane] = mine;
-  if (ncand < 2) return;  // warm-up rows and single-successor expansions need no model call (search.py:302)
   const int rid = it[IT_RID], des = it[IT_DES];
+  if (ncand < 2) return;  // warm-up rows and single-successor expansions need no model call (search.py:302)
   const float lp_parent = __int_as_float(it[IT_LP]);
   const int hp = m.hp, J = hp / 64;
-  const float* htop = D.e.h[m.n_layers - 1] + (size_t)b * D.e.exp_cap * hp;
-  const int32_t* em = D.e.exp_meta + (size_t)b * D.e.exp_cap * EM_WORDS;
-  const int depth = em[(size_t)e * EM_WORDS + EM_DEPTH];  // = number of rows on the ancestor chain incl. e
+  const float* htop = D.e.h[m.n_layers - 1];
+  const int depth = it[IT_DEPTH];  // = number of rows on the ancestor chain incl. e
   float q[JT];
   load_row<JT, SPLIT>(htop + (size_t)e * hp, q, J, lane);
   AttnAcc<JT> acc;
@@ -396,8 +464,57 @@ __global__ __launch_bounds__(256) void frontier_kernel(EngineDev D, int superste
   int have_best = S[SS_HAVE_BEST], npop = S[SS_NPOP];
   // statistics: kept in registers for the launch (a read-modify-write on S[] is a dependent round trip each)
   int st_evals = S[SS_ST_EVALS], st_cand = S[SS_ST_CAND], st_chain = S[SS_ST_CHAIN];
-  int st_skipped = S[SS_ST_SKIPPED], st_items = S[SS_ST_ITEMS];
+  int st_skipped = S[SS_ST_SKIPPED], st_items = S[SS_ST_ITEMS], st_stalls = S[SS_ST_STALLS];
   int err = 0;
+  // state pages (include/tsg.h, tsg_engine): this search's page list, the shared free ring, control words
+  int pages_held = S[SS_PAGES];
+  int32_t* my_pages = D.e.slot_pages + (size_t)b * D.e.pages_per_slot;
+  int32_t* pc = D.e.counters;
+  const int ss_stamp = pc[PC_SUPERSTEP] + 1;
+  const int tail_snap = pc[PC_TAIL_SNAP], rtail_snap = pc[PC_RTAIL_SNAP];
+  const int abort_level = pc[PC_ABORT_LEVEL];
+  const bool active_at_entry = phase != PH_IDLE;
+  const unsigned n_pages_u = (unsigned)D.e.n_pages;
+  const unsigned retry_cap_u = (unsigned)(D.e.retry_bytes / 4);
+  // make sure the state row of expansion index `idx` exists; false = no free page right now
+  auto ensure_page = [&](int idx) -> bool {
+    if (pages_held > (idx >> TSG_PAGE_SHIFT)) return true;
+    if (pc[PC_HEAD] >= tail_snap) return false;  // cheap look before the atomic
+    const int i = atomicAdd(&pc[PC_HEAD], 1);
+    if (i >= tail_snap) return false;            // overshoot, clamped by the control step
+    my_pages[pages_held++] = D.e.page_ring[(unsigned)i % n_pages_u];
+    return true;
+  };
+  auto release_pages = [&]() {
+    if (pages_held > 0) {
+      const int j = atomicAdd(&pc[PC_TAIL], pages_held);
+      // sixteen page ids per round trip (a load behind every store would make this one round trip per page,
+      // and the whole launch waits for the searches that end in it)
+      for (int k0 = 0; k0 < pages_held; k0 += 16) {
+        int p[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) p[u] = my_pages[k0 + u < pages_held ? k0 + u : pages_held - 1];
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+          if (k0 + u < pages_held) D.e.page_ring[(unsigned)(j + k0 + u) % n_pages_u] = p[u];
+      }
+      pages_held = 0;
+    }
+  };
+  // a search that found no free page: wait, or (deadlock control) give the pages back and queue again
+  auto stall = [&]() {
+    D.e.page_flags[TSG_FLAG_PLANE + (b & 255) * 32] = ss_stamp;
+    ++st_stalls;
+    if (abort_level > 0 && pages_held <= abort_level && active_at_entry && pc[PC_ABORT_BUDGET] > 0 &&
+        atomicSub(&pc[PC_ABORT_BUDGET], pages_held + 1) > 0) {
+      release_pages();
+      const int j = atomicAdd(&pc[PC_RTAIL], 1);
+      D.e.retry[(unsigned)j % retry_cap_u] = odi;
+      atomicAdd(&pc[PC_ABORTS], 1);
+      phase = PH_IDLE;
+    }
+    my_item[IT_SLOT] = -1;
+  };
 
 #if TSG_STAMP
   long long st_acc[16] = {0};
@@ -516,12 +633,27 @@ __global__ __launch_bounds__(256) void frontier_kernel(EngineDev D, int superste
         my_item[IT_SLOT] = -1;
         break;
       }
-      odi = atomicAdd(&shared[CT_NEXT_OD], 1);
-      if (odi >= od.n_od) {
-        phase = PH_DONE;
+      // admission: closed while the page pool is short; the first search of slot b waits for its place on the
+      // start-up ramp; OD pairs that were sent back come first.  (Plain loads decide whether the atomic is
+      // worth issuing: thousands of idle slots must not hammer one address.)
+      int take = -1;
+      const bool ramp_ok = gen > 0 || (long long)b * D.e.ramp_steps <= (long long)(ss_stamp - 1) * D.e.slots;
+      const bool pending = pc[PC_RHEAD] < rtail_snap || shared[CT_NEXT_OD] < od.n_od;
+      if (pending && ramp_ok && pc[PC_ADMIT_QUOTA] > 0 && atomicSub(&pc[PC_ADMIT_QUOTA], 1) > 0) {
+        if (pc[PC_RHEAD] < rtail_snap) {
+          const int i = atomicAdd(&pc[PC_RHEAD], 1);
+          if (i < rtail_snap) take = D.e.retry[(unsigned)i % retry_cap_u];
+        }
+        if (take < 0 && shared[CT_NEXT_OD] < od.n_od) {
+          const int i = atomicAdd(&shared[CT_NEXT_OD], 1);
+          if (i < od.n_od) take = i;
+        }
+      }
+      if (take < 0) {  // nothing to start now: stay idle (sent-back OD pairs may still arrive)
         my_item[IT_SLOT] = -1;
         break;
       }
+      odi = take;
       // ---- start a new search (search.py:255-278)
       ++gen;
       poff = od.prefix_ptr[odi];
@@ -564,21 +696,33 @@ __global__ __launch_bounds__(256) void frontier_kernel(EngineDev D, int superste
       phase = plen > 1 ? PH_WARMUP : PH_SEARCH;
     }
     if (phase == PH_WARMUP) {  // run the recurrent cell over the known prefix, one element per superstep
+      if (!ensure_page(warm_k)) {
+        stall();
+        break;
+      }
       const int k = warm_k++;
       int32_t* it = my_item;
       it[IT_SLOT] = b;
-      it[IT_EXP] = k;
-      it[IT_PARENT] = k - 1;
+      it[IT_ROW] = my_pages[k >> TSG_PAGE_SHIFT] * TSG_PAGE_ROWS + (k & (TSG_PAGE_ROWS - 1));
+      it[IT_PROW] = k > 0 ? my_pages[(k - 1) >> TSG_PAGE_SHIFT] * TSG_PAGE_ROWS + ((k - 1) & (TSG_PAGE_ROWS - 1)) : -1;
       it[IT_RID] = od.prefix_rid[poff + k];
       it[IT_TCODE] = od.prefix_time[poff + k];
       it[IT_NCAND] = 0;
       it[IT_DES] = des;
       it[IT_LP] = 0;
+      it[IT_DEPTH] = k + 1;
       st_items += 1;
+      D.e.page_flags[(b & 255) * 32] = ss_stamp;
       if (warm_k >= plen - 1) phase = PH_SEARCH;
       emitted = true;
       break;
     }
+    // the next expansion needs a state row: have its page before anything is popped
+    if (heap_n > 0 && step < max_step && !ensure_page(exp_n)) {
+      stall();
+      break;
+    }
+    const int row_page = pages_held > (exp_n >> TSG_PAGE_SHIFT) ? my_pages[exp_n >> TSG_PAGE_SHIFT] : 0;
     // ---- PH_SEARCH: pop until a node can be expanded (search.py:279-300)
     int fin_status = -1, fin_parent = -1, fin_rid = -1, fin_tcode = 0, fin_depth = 0;
     bool yielded = false;
@@ -602,6 +746,7 @@ __global__ __launch_bounds__(256) void frontier_kernel(EngineDev D, int superste
       const int parent = nd[ND_PARENT];
       const int date_time = nd[ND_DATE_TIME];
       const int depth = (parent >= 0 ? em[(size_t)parent * EM_WORDS + EM_DEPTH] : 0) + 1;
+      const int ppage = parent >= 0 ? my_pages[parent >> TSG_PAGE_SHIFT] : 0;  // asked for here, needed when the item is written
       const int tcode = date_time / 60 + woff;
       if (od.poplog_cap > 0 && npop < od.poplog_cap) {
         od.poplog_rid[(size_t)odi * od.poplog_cap + npop] = rid;
@@ -693,14 +838,16 @@ __global__ __launch_bounds__(256) void frontier_kernel(EngineDev D, int superste
       }
       int32_t* it = my_item;
       it[IT_SLOT] = b;
-      it[IT_EXP] = e;
+      it[IT_ROW] = row_page * TSG_PAGE_ROWS + (e & (TSG_PAGE_ROWS - 1));
       st_items += 1;
-      it[IT_PARENT] = parent;
+      it[IT_PROW] = parent >= 0 ? ppage * TSG_PAGE_ROWS + (parent & (TSG_PAGE_ROWS - 1)) : -1;
       it[IT_RID] = rid;
       it[IT_TCODE] = tcode;
       it[IT_NCAND] = C;
       it[IT_DES] = des;
       it[IT_LP] = nd[ND_LP];
+      it[IT_DEPTH] = depth;
+      D.e.page_flags[(b & 255) * 32] = ss_stamp;
       phase = PH_EXPANDED;
       emitted = true;
       CKPT(5);
@@ -755,6 +902,8 @@ __global__ __launch_bounds__(256) void frontier_kernel(EngineDev D, int superste
       atomicAdd(&shared[CT_EXPANSIONS], step);
       atomicAdd(&shared[CT_FINISHED], 1);
     }
+    release_pages();
+    D.e.page_flags[(b & 255) * 32] = ss_stamp;
     phase = PH_IDLE;
     CKPT(11);
   }
@@ -768,6 +917,7 @@ __global__ __launch_bounds__(256) void frontier_kernel(EngineDev D, int superste
       od.out_steps[odi] = step;
       atomicAdd(&shared[CT_FINISHED], 1);
     }
+    release_pages();
     phase = PH_IDLE;
   }
   CKPT(2);
@@ -801,6 +951,8 @@ __global__ __launch_bounds__(256) void frontier_kernel(EngineDev D, int superste
   S[SS_ST_CHAIN] = st_chain;
   S[SS_ST_SKIPPED] = st_skipped;
   S[SS_ST_ITEMS] = st_items;
+  S[SS_ST_STALLS] = st_stalls;
+  S[SS_PAGES] = pages_held;
 }
 
 // =====================================================================================
@@ -821,8 +973,15 @@ static int check_engine(const tsg_model* m, const tsg_graph* g, const tsg_od_bat
   if (!e->exp_meta || e->exp_meta_bytes < B * e->exp_cap * EM_WORDS * 4) return TSG_E_TOO_SMALL;
   if (!e->items || e->items_bytes < B * IT_WORDS * 4) return TSG_E_TOO_SMALL;
   if (!e->cand_lp || e->cand_lp_bytes < B * (size_t)g->max_degree * 4) return TSG_E_TOO_SMALL;
-  if (!e->counters || e->counters_bytes < 16 * 4) return TSG_E_TOO_SMALL;
-  if (!e->shared_counters) return TSG_E_INVALID;
+  if (!e->counters || e->counters_bytes < PC_WORDS * 4) return TSG_E_TOO_SMALL;
+  if (!e->shared_counters || e->shared_counters == e->counters) return TSG_E_INVALID;
+  if (e->pages_per_slot != tsg_cdiv(e->exp_cap, TSG_PAGE_ROWS)) return TSG_E_INVALID;
+  if (e->n_pages < e->pages_per_slot || e->n_pages > (1 << 24)) return TSG_E_INVALID;  // one search must always fit
+  if (e->admit_reserve < 0 || e->ramp_steps < 0) return TSG_E_INVALID;
+  if (!e->slot_pages || e->slot_pages_bytes < B * e->pages_per_slot * 4) return TSG_E_TOO_SMALL;
+  if (!e->page_ring || e->page_ring_bytes < (size_t)e->n_pages * 4) return TSG_E_TOO_SMALL;
+  if (!e->retry || e->retry_bytes < B * 4) return TSG_E_TOO_SMALL;
+  if (!e->page_flags || e->page_flags_bytes < 2 * TSG_FLAG_PLANE * 4) return TSG_E_TOO_SMALL;
   if (m) {
     if (m->hp <= 0 || (m->hp % 64) != 0 || m->hp > 512) return TSG_E_INVALID;
     if (m->n_layers < 1 || m->n_layers > TSG_MAX_LAYERS) return TSG_E_INVALID;
@@ -836,9 +995,10 @@ static int check_engine(const tsg_model* m, const tsg_graph* g, const tsg_od_bat
       for (int l = 1; l < m->n_layers; ++l)
         if (!m->wl_s[l]) return TSG_E_INVALID;
     }
-    if (!e->exp_up || e->exp_up_bytes < B * e->exp_cap * (size_t)e->up_levels * 4) return TSG_E_TOO_SMALL;
+    const size_t rows = (size_t)e->n_pages * TSG_PAGE_ROWS;
+    if (!e->exp_up || e->exp_up_bytes < rows * (size_t)e->up_levels * 4) return TSG_E_TOO_SMALL;
     for (int l = 0; l < m->n_layers; ++l)
-      if (!e->h[l] || !e->c[l] || e->state_bytes < B * e->exp_cap * (size_t)m->hp * 4) return TSG_E_TOO_SMALL;
+      if (!e->h[l] || !e->c[l] || e->state_bytes < rows * (size_t)m->hp * 4) return TSG_E_TOO_SMALL;
   }
   if (od) {
     if (od->n_od < 0 || od->lmax <= 0) return TSG_E_INVALID;
@@ -847,6 +1007,7 @@ static int check_engine(const tsg_model* m, const tsg_graph* g, const tsg_od_bat
     if (!od->out_rid || !od->out_time || !od->out_len || !od->out_status || !od->out_steps) return TSG_E_INVALID;
     if (od->poplog_cap > 0 && (!od->poplog_rid || !od->poplog_prio || !od->poplog_n)) return TSG_E_INVALID;
     if (od->allow_label && !g->label) return TSG_E_INVALID;
+    if (e->retry_bytes < ((size_t)od->n_od + B) * 4) return TSG_E_TOO_SMALL;
   }
   return 0;
 }
@@ -857,7 +1018,9 @@ extern "C" int tsg_engine_reset(const tsg_engine* e, const tsg_graph* g, void* s
   hipStream_t s = (hipStream_t)stream;
   TSG_HIP_TRY(hipMemsetAsync(e->slot_state, 0, (size_t)e->slots * SS_WORDS * 4, s));  // phase IDLE, gen 0
   TSG_HIP_TRY(hipMemsetAsync(e->table, 0, (size_t)e->slots * g->n_roads * 4, s));
-  TSG_HIP_TRY(hipMemsetAsync(e->counters, 0, 16 * 4, s));
+  TSG_HIP_TRY(hipMemsetAsync(e->page_flags, 0, 2 * TSG_FLAG_PLANE * 4, s));
+  hipLaunchKernelGGL(engine_init_pages_kernel, dim3(tsg_cdiv(e->n_pages, 256)), dim3(256), 0, s, *e);
+  TSG_LAUNCH_CHECK();
   return 0;
 }
 
@@ -870,6 +1033,8 @@ extern "C" int tsg_frontier_expand_select(const tsg_graph* g, const tsg_od_batch
   D.g = *g;
   D.od = *od;
   hipLaunchKernelGGL(frontier_kernel, dim3(tsg_cdiv(e->slots, 4 * TSG_SPW)), dim3(256), 0, (hipStream_t)stream, D, superstep);
+  TSG_LAUNCH_CHECK();
+  hipLaunchKernelGGL(engine_control_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, D);  // tsg_engine_run does this in cand_dis
   TSG_LAUNCH_CHECK();
   return 0;
 }

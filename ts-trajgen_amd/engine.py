@@ -322,19 +322,21 @@ class GraphTables(object):
 class AStarEngine(object):
     """Workspaces + superstep loop of the batched A* (tsg_engine_run).
 
-    `streams` sub-engines share one OD queue (tsg_engine.shared_counters) and run on their own HIP streams:
-    while one sub-engine is in its latency-bound frontier / scoring kernels, another keeps the matrix cores
-    busy with its LSTM step.  Workspaces are disjoint slices of the same tensors."""
+    The recurrent state of expanded nodes lives in pages of 64 rows drawn from one pool (see __init__ and
+    include/tsg.h); `streams` is accepted for compatibility and ignored (one engine per device)."""
+
+    PAGE_ROWS = 64      # TSG_PAGE_ROWS
 
     def __init__(self, tables, graph, slots, max_step, max_prefix=1, lmax=256, streams=1, prune=True, use_graph=True,
-                 state_format=1, max_pops=None):
+                 state_format=1, max_pops=None, pool_pages=None, admit_reserve=None, ramp_steps=0):
+        """pool_pages: state pages (64 rows each) shared by all searches; None reserves the worst case
+        (slots * ceil(exp_cap / 64): no search ever waits).  A smaller pool lets more searches fit in HBM (a
+        search holds only the pages it has filled); see include/tsg.h, tsg_engine."""
         self.tables, self.graph = tables, graph
         dev = self.device = tables.device
         n = graph.num_roads
-        streams = max(1, min(int(streams), int(slots)))
-        self.n_sub = streams
-        self.sub_slots = int(slots) // streams
-        self.slots = B = self.sub_slots * streams
+        self.n_sub = 1          # one engine per device (sub-engines on side streams bought nothing: DESIGN.md)
+        self.sub_slots = self.slots = B = int(slots)
         self.max_step, self.max_prefix, self.lmax = int(max_step), int(max_prefix), int(lmax)
         self.exp_cap = self.max_prefix + self.max_step
         if max_pops is None:
@@ -346,6 +348,15 @@ class AStarEngine(object):
             raise ValueError('node_cap %d exceeds 2^20-1' % self.node_cap)
         hp, nl = tables.hp, tables.n_layers
         i32, f32 = torch.int32, torch.float32
+        self.pages_per_slot = pps = (self.exp_cap + self.PAGE_ROWS - 1) // self.PAGE_ROWS
+        self.n_pages = int(pool_pages) if pool_pages is not None else B * pps
+        if self.n_pages < pps:
+            raise ValueError('the page pool must hold at least one whole search (%d pages)' % pps)
+        self.n_pages = min(self.n_pages, B * pps)
+        self.admit_reserve = int(admit_reserve) if admit_reserve is not None else (
+            0 if self.n_pages == B * pps else max(pps, self.n_pages // 12))
+        self.ramp_steps = int(ramp_steps)
+        rows = self.n_pages * self.PAGE_ROWS
         self.slot_state = torch.zeros((B, 40), dtype=i32, device=dev)
         self.heap = torch.empty((B, self.heap_cap), dtype=torch.int64, device=dev)
         self.table = torch.zeros((B, n), dtype=i32, device=dev)
@@ -354,46 +365,63 @@ class AStarEngine(object):
         self.up_levels = 64     # TSG_UP_LEVELS: ancestors listed per expanded node
         w1 = float(tables.hparams[41])
         self.prune_spread = (abs(1.0 - w1) + abs(w1)) * (1.0 + 1e-6) if prune else 0.0
-        self.exp_up = torch.empty((B, self.exp_cap, self.up_levels), dtype=i32, device=dev)
-        self.h = [torch.empty((B * self.exp_cap, hp), dtype=f32, device=dev) for _ in range(nl)]
-        self.c = [torch.empty((B * self.exp_cap, hp), dtype=f32, device=dev) for _ in range(nl)]
-        self.items = torch.empty((B, 8), dtype=i32, device=dev)
+        self.exp_up = torch.empty((rows, self.up_levels), dtype=i32, device=dev)
+        self.h = [torch.empty((rows, hp), dtype=f32, device=dev) for _ in range(nl)]
+        self.c = [torch.empty((rows, hp), dtype=f32, device=dev) for _ in range(nl)]
+        self.slot_pages = torch.empty((B, pps), dtype=i32, device=dev)
+        self.page_ring = torch.empty(self.n_pages, dtype=i32, device=dev)
+        self.retry = None       # sized per OD batch in run()
+        self.page_flags = torch.zeros((2, 256, 32), dtype=i32, device=dev)
+        self.items = torch.empty((B, 12), dtype=i32, device=dev)
         self.cand_lp = torch.empty((B, graph.max_degree), dtype=f32, device=dev)
-        self.counters = torch.zeros((streams + 1, 16), dtype=i32, device=dev)   # row `streams` = shared
-        self.c_engines = []
-        sb = self.sub_slots
-        for k in range(streams):
-            e = _lib.Engine()
-            e.slots, e.exp_cap, e.node_cap, e.heap_cap = sb, self.exp_cap, self.node_cap, self.heap_cap
-            for name in ('slot_state', 'heap', 'table', 'nodes', 'exp_meta', 'exp_up', 'items', 'cand_lp'):
-                t = getattr(self, name)[k * sb:(k + 1) * sb]
-                setattr(e, name, t.data_ptr())
-                setattr(e, name + '_bytes', t.numel() * t.element_size())
-            for l in range(nl):
-                e.h[l] = self.h[l][k * sb * self.exp_cap:].data_ptr()
-                e.c[l] = self.c[l][k * sb * self.exp_cap:].data_ptr()
-            e.state_bytes = sb * self.exp_cap * hp * 4
-            e.up_levels = self.up_levels
-            e.prune_spread = self.prune_spread
-            e.state_format = int(state_format)
-            e.max_pops = self.max_pops
-            e.counters = self.counters[k].data_ptr()
-            e.counters_bytes = 64
-            e.shared_counters = self.counters[streams].data_ptr()
-            self.c_engines.append(e)
-        self.side_streams = [torch.cuda.Stream(device=dev) for _ in range(streams)]
+        self.counters = torch.zeros((2, 16), dtype=i32, device=dev)   # row 0: page control, row 1: OD queue / totals
+        e = _lib.Engine()
+        e.slots, e.exp_cap, e.node_cap, e.heap_cap = B, self.exp_cap, self.node_cap, self.heap_cap
+        for name in ('slot_state', 'heap', 'table', 'nodes', 'exp_meta', 'exp_up', 'items', 'cand_lp', 'slot_pages',
+                     'page_ring', 'page_flags'):
+            t = getattr(self, name)
+            setattr(e, name, t.data_ptr())
+            setattr(e, name + '_bytes', t.numel() * t.element_size())
+        for l in range(nl):
+            e.h[l] = self.h[l].data_ptr()
+            e.c[l] = self.c[l].data_ptr()
+        e.state_bytes = rows * hp * 4
+        e.n_pages, e.pages_per_slot = self.n_pages, pps
+        e.admit_reserve, e.ramp_steps = self.admit_reserve, self.ramp_steps
+        e.up_levels = self.up_levels
+        e.prune_spread = self.prune_spread
+        e.state_format = int(state_format)
+        e.max_pops = self.max_pops
+        e.counters = self.counters[0].data_ptr()
+        e.counters_bytes = 64
+        e.shared_counters = self.counters[1].data_ptr()
+        self.c_engines = [e]
+        self.side_streams = [torch.cuda.Stream(device=dev)]
         self.use_graph = bool(use_graph) and os.environ.get('TSG_NO_GRAPH', '') != '1'   # env: diagnostics only
         self.state_format = int(state_format)
-        self._pinned = [torch.zeros((streams + 1, 16), dtype=i32).pin_memory() for _ in range(2)]
+        self._pinned = [torch.zeros((2, 16), dtype=i32).pin_memory() for _ in range(2)]
         self.last_stats = {}
 
     @staticmethod
-    def bytes_per_slot(tables, graph, max_step, max_prefix=1):
+    def fixed_bytes_per_slot(graph, max_step, max_prefix=1):
+        """Per-search workspaces other than state pages: queue, node records, rid table, expansion records."""
         exp_cap = max_prefix + max_step
         node_cap = min(graph.num_roads, 1 + max_step * graph.max_degree) + 1
         heap_cap = 1 + max_step * graph.max_degree
-        return (2 * tables.n_layers * exp_cap * tables.hp * 4 + heap_cap * 8 + graph.num_roads * 4
-                + node_cap * 32 + exp_cap * (16 + 4 * 64) + 40 * 4 + 32 + graph.max_degree * 4)
+        pps = (exp_cap + 63) // 64
+        return heap_cap * 8 + graph.num_roads * 4 + node_cap * 32 + exp_cap * 16 + pps * 4 + 40 * 4 + 48 \
+            + graph.max_degree * 4
+
+    @staticmethod
+    def bytes_per_page(tables):
+        """One state page: 64 rows of (h, c) per layer + the 64-entry ancestor list of each row."""
+        return 64 * (2 * tables.n_layers * tables.hp * 4 + 64 * 4)
+
+    @staticmethod
+    def bytes_per_slot(tables, graph, max_step, max_prefix=1):
+        """Worst-case reservation: the fixed workspaces plus ceil(exp_cap / 64) state pages."""
+        pps = (max_prefix + max_step + 63) // 64
+        return AStarEngine.fixed_bytes_per_slot(graph, max_step, max_prefix) + pps * AStarEngine.bytes_per_page(tables)
 
     @torch.no_grad()
     def run(self, prefix_ptr, prefix_rid, prefix_time, des, default_len, max_step, allow_label=None,
@@ -454,6 +482,9 @@ class AStarEngine(object):
             pl_n = torch.zeros(n_od, dtype=i32, device=dev)
             od.poplog_rid, od.poplog_prio, od.poplog_n = _lib.ptr(pl_rid), _lib.ptr(pl_prio), _lib.ptr(pl_n)
         m, g = self.tables.c_model, self.graph.c_graph
+        self.retry = torch.empty(n_od + self.slots, dtype=i32, device=dev)
+        self.c_engines[0].retry = self.retry.data_ptr()
+        self.c_engines[0].retry_bytes = self.retry.numel() * 4
         K = self.n_sub
         main = torch.cuda.current_stream(dev)
         streams = self.side_streams
@@ -477,7 +508,9 @@ class AStarEngine(object):
             per_search = self.max_step + self.max_prefix + 2
             if self.max_pops > 0:       # yields: at most heap_cap pops per search, max_pops of them per superstep
                 per_search += self.heap_cap // self.max_pops + 1
-            bound = (math.ceil(n_od / self.slots) + 1) * per_search + 8
+            bound = (math.ceil(n_od / self.slots) + 1) * per_search + 8 + self.ramp_steps
+            if self.n_pages < self.slots * self.pages_per_slot:     # searches may wait for pages or restart
+                bound = 4 * bound + 8 * math.ceil(n_od * self.pages_per_slot / self.n_pages) * per_search
             while True:
                 if profile_every and chunk_i % profile_every == 0:
                     # sampled chunk: drain every stream, then time each sub-engine's kernels on their own
@@ -547,7 +580,8 @@ class AStarEngine(object):
                            'n_od': n_od, 'items': int(st[32]),
                            'chain_sum': int(st[29]), 'cand_sum': int(st[28]), 'skipped_all_closed': int(st[31]),
                            'prof_ms': list(prof_ms), 'prof_launches': list(prof_n), 'prof_items': prof_items,
-                           'sub_engines': K}
+                           'sub_engines': K, 'page_waits': int(st[34]), 'restarts': int(cnt[0, 7]),
+                           'pool_pages': self.n_pages, 'min_free_pages': int(cnt[0, 12])}
         res = {'rid': out_rid, 'time': out_time, 'len': out_len, 'status': out_status, 'steps': out_steps}
         if poplog_cap > 0:
             res.update({'poplog_rid': pl_rid, 'poplog_prio': pl_prio, 'poplog_n': pl_n})

@@ -49,14 +49,16 @@ class Searcher(object):
                                       self.road_time_distribution)
         return self._graph
 
-    def _engine(self, gen_model, slots, max_step, max_prefix, lmax, streams=1):
+    def _engine(self, gen_model, slots, max_step, max_prefix, lmax, streams=1, pool_pages=None, admit_reserve=None,
+                ramp_steps=0):
         tables = gen_model.tables()
-        key = (id(tables), slots, max_step, max_prefix, lmax, streams, self.state_format)
+        key = (id(tables), slots, max_step, max_prefix, lmax, self.state_format, pool_pages, admit_reserve, ramp_steps)
         eng = self._engines.get(key)
         if eng is None:
             self._engines.clear()       # one engine's workspaces at a time
             eng = AStarEngine(tables, self.graph(), slots, max_step, max_prefix, lmax, streams,
-                              state_format=self.state_format)
+                              state_format=self.state_format, pool_pages=pool_pages, admit_reserve=admit_reserve,
+                              ramp_steps=ramp_steps)
             self._engines[key] = eng
         return eng
 
@@ -64,13 +66,15 @@ class Searcher(object):
     @torch.no_grad()
     def generate(self, gen_model, start_rids, start_times, des_rids, default_lens, max_step=500, prefixes=None,
                  allow_label=None, slots=None, lmax=256, poplog_cap=0, return_device=False, profile_every=0,
-                 streams=None):
+                 streams=None, pool_pages=None, admit_reserve=None, ramp_steps=0):
         """Road-level A* for many OD pairs.
 
         start_rids/start_times/des_rids/default_lens: int arrays of length n (prefix = one element), or pass
         `prefixes` = list of (loc_list, tim_list) for multi-element prefixes (astar_search_in_region legs).
         max_step: int or per-OD array.  Returns dict with padded `rid`/`time` [n, lmax], `len`, `status`,
-        `steps` (torch tensors)."""
+        `steps` (torch tensors).
+        pool_pages / admit_reserve / ramp_steps: state-page pool of the engine (AStarEngine.__init__); the default
+        reserves the worst case for every search in flight."""
         des = np.asarray(des_rids, dtype=np.int32)
         n_od = len(des)
         if prefixes is None:
@@ -92,7 +96,8 @@ class Searcher(object):
             slots = _auto_slots(tables, self.graph(), ms_cap, max_prefix, n_od, self.device)
         if streams is None:
             streams = 1
-        eng = self._engine(gen_model, int(slots), ms_cap, max_prefix, lmax, int(streams))
+        eng = self._engine(gen_model, int(slots), ms_cap, max_prefix, lmax, int(streams), pool_pages, admit_reserve,
+                           ramp_steps)
         dl = np.asarray(default_lens, dtype=np.int32)
         al = None if allow_label is None else np.broadcast_to(np.asarray(allow_label, dtype=np.int32), (n_od,))
         # a slot serves at most TSG_GEN_MAX searches per batch (rid-table generations): split huge batches
