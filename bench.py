@@ -82,11 +82,12 @@ def build_model(net, device):
     return model, cfg
 
 
-def pmc_traffic(kernel, lstm):
+def pmc_traffic(kernel, lstm, rows_per_launch):
     """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/pmc_traffic.json, written by
     tools/gpu_profile.sh + tools/pmc_summary.py: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this
     same bench at 8192 OD pairs, corrected as MI355X_MICROARCH.md prescribes).  Counters cannot be read from
-    inside the timed run, so this is the figure of that pass, not of this run; None when absent."""
+    inside the timed run: the figure of that pass is scaled from its work items per launch to this run's (every
+    kernel's traffic is per work item); None when absent."""
     path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
     if not os.path.exists(path):
         return None, None
@@ -98,9 +99,14 @@ def pmc_traffic(kernel, lstm):
     e = js.get(names.get(kernel, kernel))
     if not e:
         return None, None
+    pass_rows = js.get('_work_items_per_launch')
+    scale = rows_per_launch / pass_rows if pass_rows else 1.0
+    note = ', scaled x%.2f from %.0f work items per launch in the PMC pass' % (scale, pass_rows) if pass_rows else ''
     if 'hbm_bytes_corrected' in e:
-        return e['hbm_bytes_corrected'], 'profiles/pmc_traffic.json: 2*FETCH_SIZE + WRITE_SIZE per launch (gfx950 correction)'
-    return e['hbm_bytes_raw'], 'profiles/pmc_traffic.json: FETCH_SIZE + WRITE_SIZE per launch, raw (narrow accesses: uncalibrated)'
+        return e['hbm_bytes_corrected'] * scale, ('profiles/pmc_traffic.json: 2*FETCH_SIZE + WRITE_SIZE per launch '
+                                                  '(gfx950 correction)' + note)
+    return e['hbm_bytes_raw'] * scale, ('profiles/pmc_traffic.json: FETCH_SIZE + WRITE_SIZE per launch, raw (narrow '
+                                        'accesses: uncalibrated)' + note)
 
 
 def gat_encoder_timing(model, net, cfg, reps=5):
@@ -287,7 +293,7 @@ def main():
         roofline = None
         if dom:
             d = kern[dom]
-            traffic, traffic_src = pmc_traffic(dom, args.lstm)
+            traffic, traffic_src = pmc_traffic(dom, args.lstm, rows_per_launch)
             roofline = {'kernel': dom, 'bound': d['bound'], 'achieved': d['achieved'], 'peak': d['peak'],
                         'unit': d['unit'], 'frac': d['frac'], 'traffic': traffic, 'traffic_source': traffic_src,
                         'avg_launch_ms': d['avg_ms'], 'rows_per_launch': rows_per_launch}
@@ -306,7 +312,7 @@ def main():
             'expansions_per_s': exp_all / dt, 'expansions_per_od': exp_all / n_done,
             'reached_frac': float((status & 0xff == 1).mean()), 'fallback_frac': float((status & 0xff == 2).mean()),
             'avg_prefix_len_scored': avg_L, 'avg_candidates_scored': avg_C,
-            'supersteps': int(sum(s['supersteps'] for s in stats)),
+            'supersteps': int(sum(s['supersteps'] for s in stats)), 'work_items': int(items),
             'page_waits': int(sum(s['page_waits'] for s in stats)), 'restarts': int(sum(s['restarts'] for s in stats)),
             'min_free_pages': int(min(s['min_free_pages'] for s in stats)),
             'roofline': roofline, 'kernels': kern, 'gat_encoder': gat, 'cpu_baseline': cpu,
