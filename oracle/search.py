@@ -2,7 +2,8 @@
 
 Follows search.py:14-52 (SearchNode), :240-424 (Searcher.astar_search), :426-612
 (astar_search_in_region), :859-934 (DoubleLayerSearcher.astar_search), :936-1117
-(region-level A*), :614-716 (road_random_sample) and :1163-1256 (region_random_sample).  ``queue.PriorityQueue`` is a locked ``heapq`` of ``(priority,
+(region-level A*), :614-716 (road_random_sample), :1163-1256 (region_random_sample) and :137-238
+(beam_search).  ``queue.PriorityQueue`` is a locked ``heapq`` of ``(priority,
 SearchNode)`` tuples; the oracle uses ``heapq`` directly with the same tuple shape so
 that exact-priority ties fall to ``SearchNode.__lt__`` on the node's *current*
 log_prob and then to heap position, as in the reference.
@@ -375,3 +376,60 @@ def region_random_sample(region_model, region_adjacent_list, region_dist, region
     if trace_loc[-1] == des:
         return trace_loc, trace_tim
     return trace_loc[:default_len], trace_tim[:default_len]
+
+
+def beam_search(model, adjacent_list, road_center_gps, trace_loc, trace_tim, des, width=15, max_step=50,
+                prob_threshold=1e-4, randint=None, dist_fn=None, info=None):
+    """search.py:137-238 (Searcher.beam_search).  Each layer expands every node of the beam (one model call per
+    node that has successors, time advancing one MINUTE per hop, :199), children that are the destination go to
+    end_beam, the others are sorted by log_prob (stable, descending) and cut to `width`; the loop stops early
+    only when end_beam holds EXACTLY `width` nodes (:215); the result is drawn uniformly among the end nodes whose
+    probability is within prob_threshold of the best (:227-238).  With no end node and an empty beam the
+    reference indexes an empty list: IndexError, as here.
+
+    ``randint(n)`` stands in for np.random.randint(n) (:237); ``info`` (dict) receives 'index_bound'."""
+    if dist_fn is None:
+        dist_fn = geodesic.candidate_dis
+    if randint is None:
+        randint = np.random.randint
+    trace_loc = list(trace_loc)
+    trace_tim = list(trace_tim)
+    des_gps = road_center_gps[str(des)]
+    start_time = trace_tim[-1]
+    weekday_off = 1440 if start_time >= 1440 else 0                       # :163-165
+    cur_beam = [_Node(trace_loc, trace_tim, trace_loc[-1], start_time - weekday_off, 0)]
+    end_beam = []
+    step = 0
+    while step < max_step:                                               # :173
+        next_beam = []
+        for node in cur_beam:
+            if str(node.rid) not in adjacent_list:                       # :178
+                continue
+            cand = adjacent_list[str(node.rid)]
+            dis = [dist_fn(des_gps, road_center_gps[str(c)]) for c in cand]               # :181-185
+            prob = model.predict(node.trace_loc, node.trace_tim, des, cand, np.asarray(dis, dtype=np.float32))
+            lp = prob.log()                                              # :194
+            lp += node.log_prob                                          # :196
+            next_time = (node.date_time + 1) % 1440                      # :199
+            new_tim = node.trace_tim + [next_time + weekday_off]
+            for i, c in enumerate(cand):
+                child = _Node(node.trace_loc + [c], new_tim, c, next_time, lp[i].item())
+                (end_beam if c == des else next_beam).append(child)      # :207-212
+        if len(end_beam) == width:                                       # :215
+            break
+        next_beam = sorted(next_beam, key=lambda x: x.log_prob, reverse=True)
+        cur_beam = next_beam[:width]
+        step += 1
+    if len(end_beam) == 0:                                               # :223
+        end_beam = cur_beam
+    end_beam = sorted(end_beam, key=lambda x: x.log_prob, reverse=True)
+    index = 1
+    best_prob = np.exp(end_beam[0].log_prob)                             # IndexError when every branch died
+    while index < len(end_beam):
+        if best_prob - np.exp(end_beam[index].log_prob) > prob_threshold:
+            break
+        index += 1
+    if info is not None:
+        info['index_bound'] = index
+    pick = int(randint(index))
+    return end_beam[pick].trace_loc, end_beam[pick].trace_tim

@@ -273,3 +273,37 @@ def test_random_sample_vs_oracle(road, road_model):
             assert near, i
             bad += 1
     assert bad <= 2
+
+
+def test_g9_beam_search(road, road_model):
+    """Searcher.beam_search (search.py:137-238) against the reference goldens: batched, then one call with the
+    reference signature and the global numpy RNG, then the reference's IndexError."""
+    from ts_trajgen_amd.search import Searcher
+    cases = load_json('g9_beam_search.json')['cases']
+    s = Searcher(DEV, road.adjacent_list, road.rid_gps, road.road_length, road.rtd)
+    same = 0
+    groups = {}
+    for i, c in enumerate(cases):
+        groups.setdefault((c['width'], c['max_step'], c['prob_threshold']), []).append(i)
+    for (w, ms, thr), idx in groups.items():
+        locs, tims, err = s.beam_search_batch(road_model, [(cases[i]['prefix_loc'], cases[i]['prefix_tim']) for i in idx],
+                                              [cases[i]['des'] for i in idx], width=w, max_step=ms, prob_threshold=thr,
+                                              seeds=[cases[i]['seed'] for i in idx])
+        for k, i in enumerate(idx):
+            c = cases[i]
+            if 'error' in c:
+                assert err[k] == c['error']
+                same += 1
+            else:
+                assert err[k] is None
+                same += int(locs[k] == c['loc'] and tims[k] == c['tim'])
+    # log-probabilities are fp32 sums of GPU logs: a near-tie in a sort may fall the other way (none today)
+    assert same >= len(cases) - 2, same
+    c = next(c for c in cases if 'loc' in c and c['index_bound'] > 1)
+    np.random.seed(c['seed'])
+    loc, tim = s.beam_search(road_model, c['prefix_loc'], c['prefix_tim'], c['des'], width=c['width'],
+                             max_step=c['max_step'], prob_threshold=c['prob_threshold'])
+    assert loc == c['loc'] and tim == c['tim']
+    c = next(c for c in cases if 'error' in c)
+    with pytest.raises(IndexError):
+        s.beam_search(road_model, c['prefix_loc'], c['prefix_tim'], c['des'], width=c['width'], max_step=c['max_step'])

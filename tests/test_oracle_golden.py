@@ -139,3 +139,24 @@ def test_inverse_cdf_choice():
     assert osr.inverse_cdf_choice(p, 0.25) == 1 and osr.inverse_cdf_choice(p, 0.7499) == 1
     assert osr.inverse_cdf_choice(p, 0.75) == 2 and osr.inverse_cdf_choice(p, 0.99999) == 2
     assert osr.inverse_cdf_choice(np.array([0.3, 0.3], dtype=np.float32), 0.9) == 1   # sums short of u: last
+
+
+def test_g9_beam_search(road):
+    """Searcher.beam_search (search.py:137-238): trajectories, the size of the final draw set and the
+    reference's IndexError when every branch dies."""
+    om = road.oracle_model()
+    cases = load_json('g9_beam_search.json')['cases']
+    assert any('error' in c for c in cases) and any(c.get('index_bound', 1) > 1 for c in cases)
+    for c in cases:
+        rs = np.random.RandomState(c['seed'])
+        info = {}
+        args = (om, road.adjacent_list, road.rid_gps, c['prefix_loc'], c['prefix_tim'], c['des'])
+        kw = dict(width=c['width'], max_step=c['max_step'], prob_threshold=c['prob_threshold'],
+                  randint=rs.randint, info=info)
+        if 'error' in c:
+            with pytest.raises(IndexError):
+                osr.beam_search(*args, **kw)
+            continue
+        loc, tim = osr.beam_search(*args, **kw)
+        assert info['index_bound'] == c['index_bound']
+        assert loc == c['loc'] and tim == c['tim']

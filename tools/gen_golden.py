@@ -419,8 +419,62 @@ def gen_random_sample(net, model, rt):
           '; draws', sum(len(c['draws']) for c in road_cases), sum(len(c['draws']) for c in region_cases))
 
 
+# ----------------------------------------------------------------------------- G9: beam search
+def gen_beam_search(net, model):
+    """Searcher.beam_search (search.py:137-238) under np.random.seed(3000 + i); stored: inputs, the returned
+    trajectory and the bound `index` of the final np.random.randint(index) (how many end nodes were within
+    prob_threshold of the best)."""
+    ref = dict(np.load(os.path.join(OUT, 'road_model.npz')))
+    for k, v in sd_np(model.function_g).items():
+        assert np.array_equal(ref['g.' + k], v), k            # same road model as G2-G8
+    searcher = ref_search.Searcher('cpu', net.adjacent_list, net.rid_gps, net.road_length,
+                                   net.road_time_distribution)
+    with open(os.path.join(OUT, 'g5_astar.json')) as f:
+        g5 = json.load(f)['cases']
+    bounds = []
+    orig_randint = np.random.randint
+
+    def recording_randint(*a, **kw):
+        bounds.append(int(a[0]))
+        return orig_randint(*a, **kw)
+    cases = []
+    np.random.randint = recording_randint
+    try:
+        for i in range(32):
+            base = g5[(i * 3) % len(g5)]
+            k = 1 if i % 3 else min(len(base['loc']), 2 + i % 3)              # prefix length
+            loc, tim = base['loc'][:k], base['tim'][:k]
+            width = [15, 3, 1, 6][i % 4]
+            max_step = [50, 12, 30, 5][(i // 4) % 4]
+            thr = 1e-4 if i % 5 else 0.5                                      # 0.5: several end nodes qualify
+            del bounds[:]
+            np.random.seed(3000 + i)
+            case = {'prefix_loc': loc, 'prefix_tim': tim, 'des': int(base['des']), 'width': width,
+                    'max_step': max_step, 'prob_threshold': thr, 'seed': 3000 + i}
+            try:
+                with torch.no_grad():
+                    o_loc, o_tim = searcher.beam_search(model, loc, tim, base['des'], width=width,
+                                                        max_step=max_step, prob_threshold=thr)
+                case.update({'loc': [int(x) for x in o_loc], 'tim': [int(x) for x in o_tim],
+                             'index_bound': bounds[-1]})
+            except IndexError:      # every branch died: the reference indexes an empty end_beam (search.py:230)
+                case.update({'error': 'IndexError'})
+            cases.append(case)
+    finally:
+        np.random.randint = orig_randint
+    with open(os.path.join(OUT, 'g9_beam_search.json'), 'w') as f:
+        json.dump({'cases': cases}, f)
+    ok = [c for c in cases if 'loc' in c]
+    print('G9 done: reached', sum(c['loc'][-1] == c['des'] for c in ok), 'of', len(cases), '; errors',
+          len(cases) - len(ok), '; index bounds', sorted(set(c['index_bound'] for c in ok)))
+
+
 if __name__ == '__main__':
     only = sys.argv[1] if len(sys.argv) > 1 else 'all'
+    if only == 'g9':                      # adds G9 next to the existing files (same deterministic world)
+        net = messy_network()
+        gen_beam_search(net, build_road_model(net))
+        sys.exit(0)
     if only == 'g8':                      # adds G8 next to the existing files (same deterministic world)
         net = messy_network()
         model = build_road_model(net)
@@ -431,5 +485,6 @@ if __name__ == '__main__':
         rt = gen_search_goldens(net, model)
         gen_double_layer(net, model, rt)
         gen_random_sample(net, model, rt)
+        gen_beam_search(net, model)
     for fn in sorted(os.listdir(OUT)):
         print(fn, os.path.getsize(os.path.join(OUT, fn)))

@@ -163,6 +163,25 @@ class Searcher(object):
         return res['loc'][0], res['tim'][0]
 
 
+    # -- beam search (search.py:137-238) -----------------------------------------------------------
+    def beam_search_batch(self, gen_model, prefixes, des, width=15, max_step=50, prob_threshold=1e-4, seeds=None,
+                          randint=None):
+        """Many beam searches at once; see beam.beam_search_batch.  Returns (locs, tims, errors)."""
+        from .beam import beam_search_batch
+        return beam_search_batch(gen_model.tables(), self.adjacent_list, self.road_center_gps, prefixes, des,
+                                 width=width, max_step=max_step, prob_threshold=prob_threshold, seeds=seeds,
+                                 randint=randint)
+
+    def beam_search(self, gen_model, trace_loc, trace_tim, des, width=15, max_step=50, prob_threshold=1e-4):
+        """Reference signature and return value; the final draw uses the global numpy RNG (search.py:237).  When
+        every branch dies the reference indexes an empty list (search.py:230): IndexError here too."""
+        locs, tims, err = self.beam_search_batch(gen_model, [(list(trace_loc), list(trace_tim))], [int(des)],
+                                                 width=width, max_step=max_step, prob_threshold=prob_threshold)
+        if err[0]:
+            raise IndexError('list index out of range')
+        return locs[0], tims[0]
+
+
 class DoubleLayerSearcher(object):
     """Two-stage search (reference: search.py:821-934): region-level A* first (search.py:936-1117), then
     road-level A* inside each region of the region path towards a border road drawn from the transfer
