@@ -42,7 +42,7 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=1)
     ap.add_argument('--warmup', type=int, default=1)
-    ap.add_argument('--config', default='porto', choices=['grid', 'porto', 'bj'])
+    ap.add_argument('--config', default='porto', choices=['grid', 'porto', 'bj', 'stress'])
     ap.add_argument('--ods', type=int, default=65536, help='OD pairs per GPU per step')
     ap.add_argument('--warmup-ods', type=int, default=4096, help='OD pairs per GPU in a warm-up step')
     ap.add_argument('--max-step', type=int, default=5000)
@@ -64,14 +64,18 @@ def build_network(name):
         return synth.street_grid_network(32), 'synthetic 32x32 street grid, N=1984'
     if name == 'porto':
         return synth.porto_scale_network(), 'Porto-scale synthetic road graph N=11095 E=25000'
+    if name == 'stress':
+        return synth.stress_network(), 'stress synthetic city N=500000 E=1250000, GAT hidden 128, max trajectory 256'
     return synth.bj_scale_network(), 'BJ-scale synthetic road graph N=40306 E=100000'
 
 
-def build_model(net, device):
+def build_model(net, device, gat_dim=None):
     import copy
     import torch
     from ts_trajgen_amd.generator import GeneratorV4
     cfg = copy.deepcopy(BJ_DIMS)
+    if gat_dim:
+        cfg['function_h']['embed_dim'] = gat_dim
     cfg['function_g']['device'] = device
     cfg['function_h']['device'] = device
     torch.manual_seed(0)
@@ -174,7 +178,8 @@ def main():
     net, net_name = build_network(args.config)
     # OD pairs for all ranks (seeded), sharded round-robin by index; BFS default_len before the GPU is touched
     n_total = args.ods * world
-    od_all = synth.make_od_pairs(net, n_total, seed=2, workers=min(16, os.cpu_count() or 1))
+    od_all = synth.make_od_pairs(net, n_total, seed=2, workers=min(16, os.cpu_count() or 1),
+                                 default_len='lattice' if args.config == 'stress' else 'hops')
     od = {k: v[rank::world].copy() for k, v in od_all.items()}
     od_warm = {k: v[:args.warmup_ods] for k, v in od.items()}
 
@@ -185,7 +190,7 @@ def main():
     if world > 1:
         dist.init_process_group('nccl', device_id=torch.device(device))
     from ts_trajgen_amd.search import Searcher
-    model, cfg = build_model(net, device)
+    model, cfg = build_model(net, device, gat_dim=128 if args.config == 'stress' else None)
     searcher = Searcher(device, net.adjacent_list, net.rid_gps, net.road_length, net.road_time_distribution)
     searcher.state_format = 1 if args.lstm == 'split' else 0
     tables = model.tables()

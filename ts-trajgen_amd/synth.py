@@ -163,6 +163,20 @@ def bj_scale_network():
     return directed_grid_network(102, n_target=40306, e_target=100000, seed=3)
 
 
+def stress_network():
+    """Config 5: N = 500 000 segments, E = 1.25 M turn edges (356 x 356 lattice)."""
+    return directed_grid_network(356, n_target=500000, e_target=1250000, seed=3)
+
+
+def lattice_default_len(net, origins, dests, cap=256):
+    """default_len for graphs too large for all-pairs BFS: lattice (Manhattan) distance between the segments'
+    start intersections + 1, clipped to [2, cap] (config 5 bounds trajectories at 256 roads)."""
+    segs = np.asarray(net.meta['segs'])
+    o, d = segs[np.asarray(origins)], segs[np.asarray(dests)]
+    hops = np.abs(o[:, 0] - d[:, 0]) + np.abs(o[:, 1] - d[:, 1]) + 1
+    return np.clip(hops, 2, cap).astype(np.int32)
+
+
 def csr_from_adjacent_list(adjacent_list, n):
     """Order-preserving CSR of the successor lists (roads absent from the dict get degree 0)."""
     indptr = np.zeros(n + 1, dtype=np.int32)
@@ -228,6 +242,8 @@ def make_od_pairs(net, n_od, seed=2, default_len='hops', unreachable_len=20, wor
     if default_len == 'hops':
         hops = hop_distance(net, o, d, workers=workers)
         dl = np.where(hops >= 0, hops + 1, unreachable_len)
+    elif default_len == 'lattice':
+        dl = lattice_default_len(net, o, d)
     else:
         dl = np.full(n_od, int(default_len))
     return {'start': o.astype(np.int32), 'des': d.astype(np.int32),
