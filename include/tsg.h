@@ -90,6 +90,9 @@ typedef struct tsg_gat_desc {
                             concat == 0 (the head mean of gat.py:109 commutes with the skip projection) */
   float* w_skip_mean;    /* workspace [FIN][F], concat == 0 only */
   size_t skip_bytes, w_skip_mean_bytes;
+  float* w_att;          /* optional workspace [FIN][2*NH]: W_h a_src[h] | W_h a_trg[h]; when given, the per-node
+                            scores are computed from x (FIN multiply-adds) instead of re-reading proj */
+  size_t w_att_bytes;
 } tsg_gat_desc;
 
 int tsg_gat_forward(const tsg_gat_desc* d, void* stream);

@@ -30,7 +30,8 @@ class GatDesc(C.Structure):
                 ('x', _p), ('w_proj_t', _p), ('w_skip_t', _p), ('a_src', _p), ('a_trg', _p), ('bias', _p),
                 ('in_ptr', _p), ('in_src', _p), ('proj', _p), ('s_src', _p), ('s_trg', _p), ('gmax', _p),
                 ('out', _p), ('proj_bytes', _sz), ('s_bytes', _sz), ('out_bytes', _sz),
-                ('skip', _p), ('w_skip_mean', _p), ('skip_bytes', _sz), ('w_skip_mean_bytes', _sz)]
+                ('skip', _p), ('w_skip_mean', _p), ('skip_bytes', _sz), ('w_skip_mean_bytes', _sz),
+                ('w_att', _p), ('w_att_bytes', _sz)]
 
 
 class Model(C.Structure):

@@ -43,6 +43,49 @@ __global__ __launch_bounds__(256) void gat_node_scores_kernel(const float* __res
   }
 }
 
+// The per-node scores without re-reading the projection (N x NH x F floats): <proj[n,h,:], a[h,:]> =
+// <x[n,:] W_h, a_h> = <x[n,:], W_h a_h>.  w_att[k][h] = sum_f W[k][h*F+f] a_src[h][f] (and a_trg in columns NH..2NH-1)
+// is FIN x 2NH numbers; the scores are then FIN multiply-adds per (node, head) on the input features.
+__global__ __launch_bounds__(256) void gat_att_weights_kernel(const float* __restrict__ w_proj_t,
+                                                              const float* __restrict__ a_src,
+                                                              const float* __restrict__ a_trg, float* __restrict__ w_att,
+                                                              int fin, int heads, int fout) {
+  const int w = blockIdx.x * 4 + (threadIdx.x >> 6);  // one wave per (k, h)
+  const int lane = threadIdx.x & 63;
+  if (w >= fin * heads) return;
+  const int k = w / heads, h = w % heads;
+  const float* row = w_proj_t + (size_t)k * heads * fout + (size_t)h * fout;
+  float ps = 0.0f, pt = 0.0f;
+  for (int f = lane; f < fout; f += 64) {
+    ps += row[f] * a_src[h * fout + f];
+    pt += row[f] * a_trg[h * fout + f];
+  }
+  ps = tsg_wave_sum(ps);
+  pt = tsg_wave_sum(pt);
+  if (lane == 0) {
+    w_att[(size_t)k * 2 * heads + h] = ps;
+    w_att[(size_t)k * 2 * heads + heads + h] = pt;
+  }
+}
+
+__global__ __launch_bounds__(256) void gat_node_scores_x_kernel(const float* __restrict__ x,
+                                                                const float* __restrict__ w_att,
+                                                                float* __restrict__ s_src, float* __restrict__ s_trg,
+                                                                int n_nodes, int heads, int fin) {
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long)n_nodes * heads) return;
+  const int n = (int)(t / heads), h = (int)(t % heads);
+  const float* xr = x + (size_t)n * fin;
+  float ps = 0.0f, pt = 0.0f;
+  for (int k = 0; k < fin; ++k) {
+    const float v = xr[k];
+    ps += v * w_att[(size_t)k * 2 * heads + h];
+    pt += v * w_att[(size_t)k * 2 * heads + heads + h];
+  }
+  s_src[t] = ps;
+  s_trg[t] = pt;
+}
+
 __global__ void gat_init_max_kernel(float* gmax) { *gmax = -INFINITY; }
 
 __global__ __launch_bounds__(256) void gat_edge_max_kernel(const int32_t* __restrict__ in_ptr,
@@ -81,17 +124,20 @@ __global__ __launch_bounds__(256) void gat_skip_mean_kernel(const float* __restr
 // (F contiguous floats each) are gathered four at a time, the whole wave reading one row coalesced, and
 // accumulated in COO order (mul, then add: gat.py:188,263).  Heads are averaged in registers; the skip
 // term (already a dense product, with the bias folded in) and ELU close the row: no LDS, no second pass.
-// VEC4: F is a multiple of 256 and lane l owns floats 4l..4l+3 of every 256-float segment (dwordx4 loads).
-template <bool VEC4>
+// VEC = 4: F is a multiple of 256 and lane l owns floats 4l..4l+3 of every 256-float segment (dwordx4 loads);
+// VEC = 2: F == 128, lane l owns floats 2l, 2l+1 (dwordx2: one load per 512-byte row); VEC = 0: any F, lane l owns
+// floats l, l+64, ...
+template <int VEC>
 __global__ __launch_bounds__(256) void gat_aggregate_kernel(tsg_gat_desc d) {
+  constexpr bool VEC4 = VEC == 4;
   const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (n >= d.n_nodes) return;
   const int F = d.fout, NH = d.heads;
   const int e0 = d.in_ptr[n], e1 = d.in_ptr[n + 1];
   const float gmax = *d.gmax;
-  const int nv = VEC4 ? F / 64 : (F + 63) / 64;  // floats per lane
-  auto col = [&](int j) { return VEC4 ? (j >> 2) * 256 + 4 * lane + (j & 3) : lane + 64 * j; };
+  const int nv = VEC4 ? F / 64 : VEC == 2 ? 2 : (F + 63) / 64;  // floats per lane
+  auto col = [&](int j) { return VEC4 ? (j >> 2) * 256 + 4 * lane + (j & 3) : VEC == 2 ? 2 * lane + j : lane + 64 * j; };
   float mean_acc[GAT_MAXJ];
 #pragma unroll
   for (int j = 0; j < GAT_MAXJ; ++j) mean_acc[j] = 0.0f;
@@ -138,6 +184,12 @@ __global__ __launch_bounds__(256) void gat_aggregate_kernel(tsg_gat_desc d) {
                 p[u][4 * q + 3] = v.w;
               }
             }
+          } else if (VEC == 2) {
+            const float2 v = *reinterpret_cast<const float2*>(row + 2 * lane);
+            p[u][0] = v.x;
+            p[u][1] = v.y;
+#pragma unroll
+            for (int j = 2; j < GAT_MAXJ; ++j) p[u][j] = 0.0f;
           } else {
 #pragma unroll
             for (int j = 0; j < GAT_MAXJ; ++j) {
@@ -225,8 +277,16 @@ extern "C" int tsg_gat_forward(const tsg_gat_desc* d, void* stream) {
     }
     if (rc) return rc;
   }
-  hipLaunchKernelGGL(gat_node_scores_kernel, dim3(tsg_cdiv((long)N * d->heads, 4)), dim3(256), 0, s, d->proj, d->a_src,
-                     d->a_trg, d->s_src, d->s_trg, d->n_nodes, d->heads, d->fout);
+  if (d->w_att && d->w_att_bytes >= (size_t)d->fin * 2 * d->heads * 4) {
+    hipLaunchKernelGGL(gat_att_weights_kernel, dim3(tsg_cdiv((long)d->fin * d->heads, 4)), dim3(256), 0, s, d->w_proj_t,
+                       d->a_src, d->a_trg, d->w_att, d->fin, d->heads, d->fout);
+    TSG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(gat_node_scores_x_kernel, dim3(tsg_cdiv((long)N * d->heads, 256)), dim3(256), 0, s, d->x,
+                       d->w_att, d->s_src, d->s_trg, d->n_nodes, d->heads, d->fin);
+  } else {  // no workspace given: the scores from the materialised projection
+    hipLaunchKernelGGL(gat_node_scores_kernel, dim3(tsg_cdiv((long)N * d->heads, 4)), dim3(256), 0, s, d->proj,
+                       d->a_src, d->a_trg, d->s_src, d->s_trg, d->n_nodes, d->heads, d->fout);
+  }
   TSG_LAUNCH_CHECK();
   hipLaunchKernelGGL(gat_init_max_kernel, dim3(1), dim3(1), 0, s, d->gmax);
   TSG_LAUNCH_CHECK();
@@ -236,9 +296,11 @@ extern "C" int tsg_gat_forward(const tsg_gat_desc* d, void* stream) {
   TSG_LAUNCH_CHECK();
   const dim3 agrid(tsg_cdiv(d->n_nodes, 4));
   if (d->fout % 256 == 0)
-    hipLaunchKernelGGL(gat_aggregate_kernel<true>, agrid, dim3(256), 0, s, *d);
+    hipLaunchKernelGGL(gat_aggregate_kernel<4>, agrid, dim3(256), 0, s, *d);
+  else if (d->fout == 128)
+    hipLaunchKernelGGL(gat_aggregate_kernel<2>, agrid, dim3(256), 0, s, *d);
   else
-    hipLaunchKernelGGL(gat_aggregate_kernel<false>, agrid, dim3(256), 0, s, *d);
+    hipLaunchKernelGGL(gat_aggregate_kernel<0>, agrid, dim3(256), 0, s, *d);
   TSG_LAUNCH_CHECK();
   return 0;
 }

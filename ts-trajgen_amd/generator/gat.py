@@ -105,6 +105,8 @@ class GATLayerImp3(nn.Module):
             if not self.concat:
                 w_mean = torch.empty((fin, fo), dtype=torch.float32, device=dev)
                 d.w_skip_mean, d.w_skip_mean_bytes = _lib.ptr(w_mean), w_mean.numel() * 4
+        w_att = torch.empty((fin, 2 * nh), dtype=torch.float32, device=dev)
+        d.w_att, d.w_att_bytes = _lib.ptr(w_att), w_att.numel() * 4
         d.proj_bytes = proj.numel() * 4
         d.s_bytes = s_src.numel() * 4
         d.out_bytes = out.numel() * 4
