@@ -438,8 +438,10 @@ __device__ __forceinline__ HeapEnt heap_pop(uint64_t* h, int& n, const int32_t* 
 // TSG_SPW searches per wave (one lane each, the other lanes idle): the work is a chain of dependent small
 // accesses, so what matters is how many chains are in flight and how long a search waits for the slowest
 // search of its wave (every divergent loop runs to the longest trip count in the wave), not lane use.
+// 8: with 24 576 searches in flight, 4 per wave are 6 144 waves = two rounds at this kernel's register count
+// (106 us per launch); 8 or 16 per wave fit in one round (91 us).
 #ifndef TSG_SPW
-#define TSG_SPW 4
+#define TSG_SPW 8
 #endif
 __global__ __launch_bounds__(256) void frontier_kernel(EngineDev D, int superstep) {
   const int b = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * TSG_SPW + (threadIdx.x & 63);
