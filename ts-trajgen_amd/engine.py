@@ -335,8 +335,7 @@ class AStarEngine(object):
         self.tables, self.graph = tables, graph
         dev = self.device = tables.device
         n = graph.num_roads
-        self.n_sub = 1          # one engine per device (sub-engines on side streams bought nothing: DESIGN.md)
-        self.sub_slots = self.slots = B = int(slots)
+        self.slots = B = int(slots)   # one engine per device (sub-engines on side streams bought nothing: DESIGN.md)
         self.max_step, self.max_prefix, self.lmax = int(max_step), int(max_prefix), int(lmax)
         self.exp_cap = self.max_prefix + self.max_step
         if max_pops is None:
@@ -485,25 +484,24 @@ class AStarEngine(object):
         self.retry = torch.empty(n_od + self.slots, dtype=i32, device=dev)
         self.c_engines[0].retry = self.retry.data_ptr()
         self.c_engines[0].retry_bytes = self.retry.numel() * 4
-        K = self.n_sub
+        eng = self.c_engines[0]
         main = torch.cuda.current_stream(dev)
-        streams = self.side_streams
-        handles = [C.c_void_p(s.cuda_stream) for s in streams]
+        stream = self.side_streams[0]            # graph capture needs a stream of its own (not the legacy default)
+        handle = C.c_void_p(stream.cuda_stream)
         supersteps = 0
         nk = 2 + _lib.TSG_MAX_LAYERS
         prof_ms = (C.c_float * nk)()
         prof_n = (C.c_int32 * nk)()
         prof_items = 0
         chunk_i = 0
-        inflight = [[] for _ in range(K)]
         pending = []
-        graphs = [None] * K
-        cnt = torch.zeros((K + 1, 16), dtype=torch.int32)
+        graph = None
+        K = 1                                    # row of `counters` with the OD queue / totals
+        cnt = torch.zeros((2, 16), dtype=torch.int32)
         with torch.cuda.device(dev):
             self.counters.zero_()
-            for k in range(K):
-                streams[k].wait_stream(main)
-                _lib.check(L.tsg_engine_reset(C.byref(self.c_engines[k]), C.byref(g), handles[k]), 'tsg_engine_reset')
+            stream.wait_stream(main)
+            _lib.check(L.tsg_engine_reset(C.byref(eng), C.byref(g), handle), 'tsg_engine_reset')
             # every superstep each unfinished slot advances by >= 1 expansion / prefix element / finished OD
             per_search = self.max_step + self.max_prefix + 2
             if self.max_pops > 0:       # yields: at most heap_cap pops per search, max_pops of them per superstep
@@ -511,67 +509,55 @@ class AStarEngine(object):
             bound = (math.ceil(n_od / self.slots) + 1) * per_search + 8 + self.ramp_steps
             if self.n_pages < self.slots * self.pages_per_slot:     # searches may wait for pages or restart
                 bound = 4 * bound + 8 * math.ceil(n_od * self.pages_per_slot / self.n_pages) * per_search
-            while True:
-                if profile_every and chunk_i % profile_every == 0:
-                    # sampled chunk: drain every stream, then time each sub-engine's kernels on their own
-                    for s in streams:
-                        s.synchronize()
-                    items0 = int(self.slot_state[:, 32].sum())
-                    for k in range(K):
-                        _lib.check(L.tsg_engine_run_profiled(C.byref(m), C.byref(g), C.byref(od),
-                                                             C.byref(self.c_engines[k]), supersteps, chunk, handles[k],
-                                                             prof_ms, prof_n), 'tsg_engine_run_profiled')
-                    cnt = self.counters.cpu()
-                    pending = []
-                    prof_items += int(self.slot_state[:, 32].sum()) - items0
-                else:
-                    # two chunks stay in flight: the completion counter of chunk i-1 is inspected (from a pinned
-                    # snapshot copied on the stream) only after chunk i has been enqueued, so the GPU never waits
-                    # for the host round trip
-                    for k in range(K):
-                        if self.use_graph and graphs[k] is None:
-                            gx = C.c_void_p()
-                            _lib.check(L.tsg_engine_graph_create(C.byref(m), C.byref(g), C.byref(od),
-                                                                 C.byref(self.c_engines[k]), chunk, handles[k],
-                                                                 C.byref(gx)), 'tsg_engine_graph_create')
-                            graphs[k] = gx
+            try:
+                while True:
+                    if profile_every and chunk_i % profile_every == 0:
+                        # sampled chunk: drain the stream, then time every kernel of the chunk with HIP events
+                        stream.synchronize()
+                        items0 = int(self.slot_state[:, 32].sum())
+                        _lib.check(L.tsg_engine_run_profiled(C.byref(m), C.byref(g), C.byref(od), C.byref(eng),
+                                                             supersteps, chunk, handle, prof_ms, prof_n),
+                                   'tsg_engine_run_profiled')
+                        cnt = self.counters.cpu()
+                        pending = []
+                        prof_items += int(self.slot_state[:, 32].sum()) - items0
+                    else:
+                        # two chunks stay in flight: the completion counter of chunk i-1 is inspected (from a pinned
+                        # snapshot copied on the stream) only after chunk i has been enqueued, so the GPU never
+                        # waits for the host round trip
                         if self.use_graph:
-                            _lib.check(L.tsg_engine_graph_launch(graphs[k], handles[k]), 'tsg_engine_graph_launch')
+                            if graph is None:
+                                gx = C.c_void_p()
+                                _lib.check(L.tsg_engine_graph_create(C.byref(m), C.byref(g), C.byref(od), C.byref(eng),
+                                                                     chunk, handle, C.byref(gx)),
+                                           'tsg_engine_graph_create')
+                                graph = gx
+                            _lib.check(L.tsg_engine_graph_launch(graph, handle), 'tsg_engine_graph_launch')
                         else:
-                            _lib.check(L.tsg_engine_run(C.byref(m), C.byref(g), C.byref(od),
-                                                        C.byref(self.c_engines[k]), supersteps, chunk, handles[k]),
-                                       'tsg_engine_run')
-                    snap = self._pinned[chunk_i % 2]
-                    with torch.cuda.stream(streams[0]):
-                        snap.copy_(self.counters, non_blocking=True)
-                    ev = torch.cuda.Event()
-                    ev.record(streams[0])
-                    pending.append((ev, snap))
-                    if K > 1:
-                        for k in range(1, K):       # bound the run-ahead on the other streams too
-                            evk = torch.cuda.Event()
-                            evk.record(streams[k])
-                            inflight[k].append(evk)
-                            if len(inflight[k]) > 2:
-                                inflight[k].pop(0).synchronize()
-                    if len(pending) >= 2:
-                        ev0, snap0 = pending.pop(0)
-                        ev0.synchronize()
-                        cnt = snap0.clone()
-                supersteps += chunk
-                chunk_i += 1
-                if int(cnt[K, 3]) >= n_od:
-                    break
-                if supersteps > bound:
-                    raise RuntimeError('A* engine did not finish within %d supersteps (finished %d of %d)'
-                                       % (bound, int(cnt[K, 3]), n_od))
-            for s in streams:
-                s.synchronize()
-            for s in streams:
-                main.wait_stream(s)
-            for gx in graphs:
-                if gx is not None:
-                    L.tsg_engine_graph_destroy(gx)
+                            _lib.check(L.tsg_engine_run(C.byref(m), C.byref(g), C.byref(od), C.byref(eng), supersteps,
+                                                        chunk, handle), 'tsg_engine_run')
+                        snap = self._pinned[chunk_i % 2]
+                        with torch.cuda.stream(stream):
+                            snap.copy_(self.counters, non_blocking=True)
+                        ev = torch.cuda.Event()
+                        ev.record(stream)
+                        pending.append((ev, snap))
+                        if len(pending) >= 2:
+                            ev0, snap0 = pending.pop(0)
+                            ev0.synchronize()
+                            cnt = snap0.clone()
+                    supersteps += chunk
+                    chunk_i += 1
+                    if int(cnt[K, 3]) >= n_od:
+                        break
+                    if supersteps > bound:
+                        raise RuntimeError('A* engine did not finish within %d supersteps (finished %d of %d)'
+                                           % (bound, int(cnt[K, 3]), n_od))
+            finally:
+                stream.synchronize()
+                main.wait_stream(stream)
+                if graph is not None:
+                    L.tsg_engine_graph_destroy(graph)
             cnt = self.counters.cpu()
         if int(cnt[K, 6]) != 0:
             raise RuntimeError('A* engine hit a workspace cap (node/heap/exp capacity)')
@@ -580,7 +566,7 @@ class AStarEngine(object):
                            'n_od': n_od, 'items': int(st[32]),
                            'chain_sum': int(st[29]), 'cand_sum': int(st[28]), 'skipped_all_closed': int(st[31]),
                            'prof_ms': list(prof_ms), 'prof_launches': list(prof_n), 'prof_items': prof_items,
-                           'sub_engines': K, 'page_waits': int(st[34]), 'restarts': int(cnt[0, 7]),
+                           'page_waits': int(st[34]), 'restarts': int(cnt[0, 7]),
                            'pool_pages': self.n_pages, 'min_free_pages': int(cnt[0, 12])}
         res = {'rid': out_rid, 'time': out_time, 'len': out_len, 'status': out_status, 'steps': out_steps}
         if poplog_cap > 0:
