@@ -239,13 +239,16 @@ class DoubleLayerSearcher(object):
         n = len(des_regions)
         res = self._regions().generate(region_model, start_regions, start_times, des_regions,
                                        np.full(n, 10, dtype=np.int32),      # best_default_len = 10 (search.py:967)
-                                       max_step=max_step, lmax=max(64, int(np.max(max_step)) + 2))
+                                       max_step=max_step,
+                                       # a region path visits a region at most once (closed set)
+                                       lmax=max(64, min(int(np.max(max_step)), self._regions().graph().num_roads) + 2))
         traces, flags = [], []
+        r_rid, r_len, r_status = res['rid'].numpy(), res['len'].numpy(), res['status'].numpy()
         for i in range(n):
-            if (int(res['status'][i]) & 0xff) == STATUS_UNTOUCHED:
+            if (int(r_status[i]) & 0xff) == STATUS_UNTOUCHED:
                 raise AssertionError('region search produced no trace (search.py:1113)')
-            k = int(res['len'][i])
-            tr = res['rid'][i, :k].tolist()
+            k = int(r_len[i])
+            tr = r_rid[i, :k].tolist()
             traces.append(tr)
             flags.append(1 if tr[-1] == int(des_regions[i]) else 0)         # search.py:1114-1117
         return traces, flags
@@ -277,7 +280,7 @@ class DoubleLayerSearcher(object):
         n = len(des_rids)
         ms = np.broadcast_to(np.asarray(max_step, dtype=np.int32), (n,)).copy()
         if rngs is None:
-            rngs = [np.random.RandomState(int(seeds[i]) if seeds is not None else i) for i in range(n)]
+            rngs = [None] * n      # RandomState(seed of OD i), made when OD i first draws (seeding costs 25 us)
         self._label_roads()
         sreg = [self.rid2region[str(int(r))] for r in start_rids]
         dreg = [self.rid2region[str(int(r))] for r in des_rids]
@@ -292,6 +295,8 @@ class DoubleLayerSearcher(object):
         attempt = [0] * n
         done = [False] * n
         rounds = expansions = 0
+        lab = self.road_search.graph().label
+        label_np = lab.cpu().numpy() if lab is not None else None      # host copy: one lookup per OD pair and round
         while True:
             act = [i for i in range(n) if not done[i]]
             if not act:
@@ -303,6 +308,8 @@ class DoubleLayerSearcher(object):
                     if order[i] is None:
                         b = self.region_transfer_freq[str(rt[leg[i]])][str(rt[leg[i] + 1])]
                         freq = np.array(b['transfer_freq'])
+                        if rngs[i] is None:
+                            rngs[i] = np.random.RandomState(int(seeds[i]) if seeds is not None else i)
                         order[i] = rngs[i].choice(b['transfer_rid'], len(b['transfer_rid']),
                                                   p=freq / np.sum(freq), replace=False)      # search.py:900-902
                         attempt[i] = 0
@@ -310,8 +317,7 @@ class DoubleLayerSearcher(object):
                     allow.append(int(rt[leg[i]]))
                 else:
                     des = int(des_rids[i])
-                    in_last = self.road_search.graph().label is not None and \
-                        int(self.road_search.graph().label[des]) == int(rt[-1])
+                    in_last = label_np is not None and int(label_np[des]) == int(rt[-1])
                     targets.append(des)
                     allow.append(int(rt[-1]) if in_last else -1)                             # search.py:925-931
             pref = [(loc[i], tim[i]) for i in act]
@@ -322,12 +328,14 @@ class DoubleLayerSearcher(object):
                                             lmax=lmax)
             expansions += self.road_search.last_stats.get('expansions', 0)
             rounds += 1
+            r_rid, r_time = res['rid'].numpy(), res['time'].numpy()       # per-OD tensor indexing would dominate
+            r_len, r_status = res['len'].numpy(), res['status'].numpy()
             for j, i in enumerate(act):
-                k = int(res['len'][j])
-                if (int(res['status'][j]) & _lib.STATUS_OVERFLOW) or k > res['rid'].shape[1]:
+                k = int(r_len[j])
+                if (int(r_status[j]) & _lib.STATUS_OVERFLOW) or k > r_rid.shape[1]:
                     raise RuntimeError('trajectory longer than the output row')
-                loc[i] = res['rid'][j, :k].tolist()
-                tim[i] = res['time'][j, :k].tolist()
+                loc[i] = r_rid[j, :k].tolist()
+                tim[i] = r_time[j, :k].tolist()
                 rt = region_traces[i]
                 if leg[i] < len(rt) - 1:
                     if loc[i][-1] == targets[j]:                         # search.py:912-914
