@@ -81,6 +81,16 @@ extern "C" int tsg_score_candidates(const tsg_model* m, const tsg_score_batch* b
   return 0;
 }
 
+// Waves per workgroup of the two kernels whose waves run for very different times (a long ancestor chain, a long
+// pop chain): a workgroup gives its registers back only when its last wave ends, so one wave per workgroup
+// lets the next work item start as soon as ANY wave ends (scoring kernel: 130 -> 115 us per launch).
+#ifndef TSG_SCORE_WPB
+#define TSG_SCORE_WPB 1
+#endif
+#ifndef TSG_FRONTIER_WPB
+#define TSG_FRONTIER_WPB 4
+#endif
+
 // =====================================================================================
 // engine scoring: one wave per work item of the current superstep
 // =====================================================================================
@@ -189,7 +199,7 @@ __global__ __launch_bounds__(256) void cand_dis_kernel(EngineDev D, int superste
 // loads.  Chains longer than 64 hop through anc[.][63] once per 64 rows.
 template <int JT, bool SPLIT>
 __global__ __launch_bounds__(256) void score_frontier_kernel(tsg_model m, EngineDev D, int superstep) {
-  const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int idx = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (idx >= D.e.slots) return;
   const int32_t* it = D.e.items + (size_t)idx * IT_WORDS;  // items are indexed by slot
@@ -278,7 +288,7 @@ static void launch_cand_dis(const EngineDev& D, int superstep, hipStream_t s) {
 
 template <bool SPLIT>
 static void launch_score_frontier_t(const tsg_model* m, const EngineDev& D, int superstep, hipStream_t s) {
-  const dim3 grid(tsg_cdiv(D.e.slots, 4)), blk(256);
+  const dim3 grid(tsg_cdiv(D.e.slots, TSG_SCORE_WPB)), blk(64 * TSG_SCORE_WPB);
   switch (jt_for(m->hp)) {
     case 1: hipLaunchKernelGGL((score_frontier_kernel<1, SPLIT>), grid, blk, 0, s, *m, D, superstep); break;
     case 2: hipLaunchKernelGGL((score_frontier_kernel<2, SPLIT>), grid, blk, 0, s, *m, D, superstep); break;
@@ -1034,7 +1044,7 @@ extern "C" int tsg_frontier_expand_select(const tsg_graph* g, const tsg_od_batch
   D.e = *e;
   D.g = *g;
   D.od = *od;
-  hipLaunchKernelGGL(frontier_kernel, dim3(tsg_cdiv(e->slots, 4 * TSG_SPW)), dim3(256), 0, (hipStream_t)stream, D, superstep);
+  hipLaunchKernelGGL(frontier_kernel, dim3(tsg_cdiv(e->slots, TSG_FRONTIER_WPB * TSG_SPW)), dim3(64 * TSG_FRONTIER_WPB), 0, (hipStream_t)stream, D, superstep);
   TSG_LAUNCH_CHECK();
   hipLaunchKernelGGL(engine_control_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, D);  // tsg_engine_run does this in cand_dis
   TSG_LAUNCH_CHECK();
@@ -1067,10 +1077,10 @@ extern "C" int tsg_engine_run(const tsg_model* m, const tsg_graph* g, const tsg_
   D.e = *e;
   D.g = *g;
   D.od = *od;
-  const dim3 fgrid(tsg_cdiv(e->slots, 4 * TSG_SPW));
+  const dim3 fgrid(tsg_cdiv(e->slots, TSG_FRONTIER_WPB * TSG_SPW));
   for (int k = 0; k < n_supersteps; ++k) {
     const int ss = first_superstep + k;
-    hipLaunchKernelGGL(frontier_kernel, fgrid, dim3(256), 0, s, D, ss);
+    hipLaunchKernelGGL(frontier_kernel, fgrid, dim3(64 * TSG_FRONTIER_WPB), 0, s, D, ss);
     TSG_LAUNCH_CHECK();
     launch_cand_dis(D, ss, s);
     TSG_LAUNCH_CHECK();
@@ -1149,13 +1159,13 @@ extern "C" int tsg_engine_run_profiled(const tsg_model* m, const tsg_graph* g, c
       delete[] ev;
       return TSG_E_INVALID;
     }
-  const dim3 fgrid(tsg_cdiv(e->slots, 4 * TSG_SPW));
+  const dim3 fgrid(tsg_cdiv(e->slots, TSG_FRONTIER_WPB * TSG_SPW));
   int q = 0;
   rc = 0;
   for (int k = 0; k < n_supersteps && rc == 0; ++k) {
     const int ss = first_superstep + k;
     (void)hipEventRecord(ev[q++], s);
-    hipLaunchKernelGGL(frontier_kernel, fgrid, dim3(256), 0, s, D, ss);
+    hipLaunchKernelGGL(frontier_kernel, fgrid, dim3(64 * TSG_FRONTIER_WPB), 0, s, D, ss);
     launch_cand_dis(D, ss, s);  // timed with the frontier kernel
     (void)hipEventRecord(ev[q++], s);
     for (int l = 0; l < m->n_layers && rc == 0; ++l) {
