@@ -267,15 +267,21 @@ typedef struct tsg_engine {
   int32_t* retry;       size_t retry_bytes;       /* [>= n_od + B] ring of OD indices waiting to restart */
   int32_t* page_flags;  size_t page_flags_bytes;  /* [2][256][32] progress / wait stamps of the superstep, spread over
                                                      256 cache lines each (gathered by the control step) */
-  int32_t* items;       size_t items_bytes;       /* [B][12] work item of each search for the current superstep
-                                                     (word 0 = slot, or -1 when the search emitted none) */
+  int32_t* items;       size_t items_bytes;       /* [R * 4096][12], R = ceil(B / 4096): the work items of the current
+                                                     superstep, a compacted list.  The searches of slots [4096 r,
+                                                     4096 r + 4096) that emit an item write it into stretch r: items
+                                                     with 16 or more rows on their ancestor chain from the front, the
+                                                     others from the back; the distance, recurrence and scoring kernels
+                                                     walk the filled positions only */
+  int32_t* item_counts; size_t item_counts_bytes; /* [2][R][32]: n_long, n_short of each stretch (one 128-byte line each),
+                                                     one plane per superstep parity */
   float* cand_lp;       size_t cand_lp_bytes;     /* [B][max_degree] */
   int32_t* shared_counters;                       /* [16] words 2,3,4,6 below; == counters for a lone engine.  Several
                                                      engines (disjoint workspaces, one HIP stream each) that work on
                                                      the SAME tsg_od_batch share this array: one OD queue */
   int32_t* counters;    size_t counters_bytes;    /* [16] state-page control of THIS engine: 0 ring head, 1 ring tail,
                                                      2 tail snapshot, 3-5 the same for `retry`, 6 waits, 7 restarts,
-                                                     8 restart level, 9-10 unused, 11 superstep,
+                                                     8 restart level, 9 plane of item_counts just filled, 10 unused, 11 superstep,
                                                      12 fewest free pages seen, 13 admission quota, 14 restart budget.
                                                      shared_counters: 2 next OD, 3 finished ODs, 4 total expansions,
                                                      6 error flag.  Per-slot statistics live in slot_state words

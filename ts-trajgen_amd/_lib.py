@@ -74,7 +74,7 @@ class Engine(C.Structure):
                 ('n_pages', _i32), ('pages_per_slot', _i32), ('admit_reserve', _i32), ('ramp_steps', _i32),
                 ('slot_pages', _p), ('slot_pages_bytes', _sz), ('page_ring', _p), ('page_ring_bytes', _sz),
                 ('retry', _p), ('retry_bytes', _sz), ('page_flags', _p), ('page_flags_bytes', _sz),
-                ('items', _p), ('items_bytes', _sz), ('cand_lp', _p), ('cand_lp_bytes', _sz),
+                ('items', _p), ('items_bytes', _sz), ('item_counts', _p), ('item_counts_bytes', _sz), ('cand_lp', _p), ('cand_lp_bytes', _sz),
                 ('shared_counters', _p), ('counters', _p), ('counters_bytes', _sz)]
 
 

@@ -55,12 +55,51 @@ enum { CT_ITEMS0 = 0, CT_ITEMS1 = 1, CT_NEXT_OD = 2, CT_FINISHED = 3, CT_EXPANSI
 // only what earlier launches produced.
 enum {
   PC_HEAD = 0, PC_TAIL, PC_TAIL_SNAP, PC_RHEAD, PC_RTAIL, PC_RTAIL_SNAP, PC_STALLS, PC_ABORTS, PC_ABORT_LEVEL,
-  PC_PROGRESS, PC_STALL_STEP, PC_SUPERSTEP, PC_MIN_FREE, PC_ADMIT_QUOTA, PC_ABORT_BUDGET, PC_WORDS = 16
+  PC_ITEM_PLANE, PC_STALL_STEP, PC_SUPERSTEP, PC_MIN_FREE, PC_ADMIT_QUOTA, PC_ABORT_BUDGET, PC_WORDS = 16
 };
-// work item words ([B][12] int32); ROW / PROW = state rows (page * 64 + offset) of the node and of its parent
+// work item words ([positions][12] int32); ROW / PROW = state rows (page * 64 + offset) of the node and of its parent
 enum { IT_SLOT = 0, IT_ROW, IT_PROW, IT_RID, IT_TCODE, IT_NCAND, IT_DES, IT_LP, IT_DEPTH, IT_WORDS = 12 };
 #define TSG_PAGE_ROWS 64
 #define TSG_PAGE_SHIFT 6
+// Work list of a superstep (tsg_engine.items).  Only part of the searches emit a work item in a superstep (the
+// others yielded, wait for a page, or are idle), so the items form a compacted list that the distance,
+// recurrence and scoring kernels walk instead of all slots.  The slots are cut into regions of
+// TSG_REGION_SLOTS; the searches of a region write into the region's own stretch of the list (one counter pair
+// per region and superstep parity in tsg_engine.item_counts, one atomic per wave): items whose ancestor chain
+// has at least TSG_LONG_DEPTH rows from the front, the others from the back, so the scoring kernel can start
+// the long chains first.  Position p of a region of rs slots is filled iff p < n_long or p >= rs - n_short.
+#define TSG_REGION_SLOTS 4096
+#ifndef TSG_LONG_DEPTH
+#define TSG_LONG_DEPTH 16
+#endif
+#define TSG_ITEM_CNT_STRIDE 32  // one 128-byte line per region: word 0 = n_long, word 1 = n_short
+__host__ __device__ inline int tsg_n_regions(int slots) { return (slots + TSG_REGION_SLOTS - 1) / TSG_REGION_SLOTS; }
+__host__ __device__ inline size_t tsg_item_positions(int slots) { return (size_t)tsg_n_regions(slots) * TSG_REGION_SLOTS; }
+__host__ __device__ inline size_t tsg_item_count_words(int slots) {  // two planes
+  return (size_t)tsg_n_regions(slots) * 2 * TSG_ITEM_CNT_STRIDE;
+}
+__host__ __device__ inline int tsg_region_size(int slots, int region) {
+  const int left = slots - region * TSG_REGION_SLOTS;
+  return left < TSG_REGION_SLOTS ? left : TSG_REGION_SLOTS;
+}
+__host__ __device__ inline size_t tsg_item_cnt_index(int slots, int plane, int region) {
+  return ((size_t)plane * tsg_n_regions(slots) + region) * TSG_ITEM_CNT_STRIDE;
+}
+// Reader side: the counters of the plane the control step published.  Both planes are loaded together with the
+// plane word (and the caller loads the item words before it knows whether the position is filled: they are
+// then stale, in range, and not used), so finding one's work item costs one round trip.
+__device__ __forceinline__ void tsg_item_counts(const int32_t* counts, const int32_t* pc, int slots, int region,
+                                                int& n_long, int& n_short) {
+  const int32_t* c0 = counts + tsg_item_cnt_index(slots, 0, region);
+  const int32_t* c1 = counts + tsg_item_cnt_index(slots, 1, region);
+  const int plane = pc[PC_ITEM_PLANE];
+  const int l0 = c0[0], s0 = c0[1], l1 = c1[0], s1 = c1[1];
+  n_long = plane ? l1 : l0;
+  n_short = plane ? s1 : s0;
+}
+__host__ __device__ inline bool tsg_item_filled(int p, int rs, int n_long, int n_short) {
+  return p < n_long || (p >= rs - n_short && p < rs);
+}
 // node record words ([B][node_cap][8] int32)
 enum { ND_RID = 0, ND_PARENT, ND_LP, ND_DATE_TIME, ND_EXP, ND_WORDS = 8 };
 enum { ND_OPEN = -1, ND_CLOSED_NOSLOT = -2 };

@@ -116,8 +116,10 @@ struct LstmArgs {
   const int64_t* out_idx;
   const int32_t* rid;
   const int32_t* tcode;
-  const int32_t* items;  // engine mode when non-null: [n][IT_WORDS]
-  int exp_cap;           // unused (engine work items carry state rows)
+  const int32_t* items;  // engine mode when non-null: the superstep's work list (tsg_common.h)
+  const int32_t* item_counts;  // engine mode: tsg_engine.item_counts
+  const int32_t* pc;     // engine mode: tsg_engine.counters
+  int slots;             // engine mode
   const float* h_below;
   float* h;
   float* c;
@@ -127,47 +129,49 @@ struct LstmArgs {
   const float* bias;   // layer >= 1
 };
 
+// Rows of one 128-row tile.  Explicit index arrays: rows [row0, row0 + 128) of the arrays.  Engine mode: the
+// tile is a stretch of 128 positions of one region of the work list (tsg_common.h); returns false when none of
+// them is filled in this superstep.  Fills s_prev / s_out (-1 = no row) and, for layer 0, s_rid / s_tc.
+static_assert(TSG_REGION_SLOTS % BM == 0, "whole row tiles per region of the work list");
 template <bool LAYER0>
-__global__ __launch_bounds__(256, 2) void lstm_layer_kernel(LstmArgs a) {
-  __shared__ TileLds tt[2];  // double-buffered k-tiles: one barrier per tile
-  __shared__ long long s_prev[BM];
-  __shared__ long long s_out[BM];
-  __shared__ int s_rid[BM];
-  __shared__ int s_tc[BM];
+__device__ __forceinline__ bool lstm_tile_rows(const LstmArgs& a, int rowtile, long long* s_prev, long long* s_out,
+                                               int* s_rid, int* s_tc) {
+  const int tid = threadIdx.x;
+  if (a.items) {
+    constexpr int TPR = TSG_REGION_SLOTS / BM;
+    const int region = rowtile / TPR, p0 = (rowtile % TPR) * BM;
+    if (region >= tsg_n_regions(a.slots)) return false;
+    const int rs = tsg_region_size(a.slots, region);
+    // item words and counters are loaded together (the words of an unfilled position are stale and dropped)
+    const int p = p0 + (tid & (BM - 1));
+    const int32_t* it = a.items + ((size_t)region * TSG_REGION_SLOTS + p) * IT_WORDS;
+    const int4 w0 = *reinterpret_cast<const int4*>(it);      // IT_SLOT, IT_ROW, IT_PROW, IT_RID
+    const int w_tc = it[IT_TCODE];
+    int n_long, n_short;
+    tsg_item_counts(a.item_counts, a.pc, a.slots, region, n_long, n_short);
+    if (!(p0 < n_long || (n_short > 0 && p0 < rs && p0 + BM > rs - n_short))) return false;  // nothing filled here
+    if (tid < BM) {
+      const bool filled = tsg_item_filled(p, rs, n_long, n_short);
+      s_prev[tid] = filled ? (long long)w0.z : -1;  // state rows (page * 64 + offset), -1 = no parent
+      s_out[tid] = filled ? (long long)w0.y : -1;
+      s_rid[tid] = filled ? w0.w : 0;
+      s_tc[tid] = filled ? w_tc : 0;
+    }
+    return true;
+  }
   const int n = a.n_rows_dev ? *a.n_rows_dev : a.n_rows_host;
-  const int hp = a.hp;
-  const int ct_n = hp / 32;  // column tiles (32 hidden units each)
-  // XCD-aware decode: the ct_n column tiles of one row tile share bid % 8 (one XCD's L2 serves the A rows)
-  const int bid = blockIdx.x;
-  const int xcd = bid & 7, within = bid >> 3;
-  const int rowtile = (within / ct_n) * 8 + xcd;
-  const int coltile = within % ct_n;
   const int row0 = rowtile * BM;
-  if (row0 >= n) return;
-#if TSG_ABLATE == 21
-  return;
-#endif
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  if (row0 >= n) return false;
   if (tid < BM) {
     const int m = row0 + tid;
     long long pv = -1, ov = -1;
     int rd = 0, tc = 0;
     if (m < n) {
-      if (a.items) {
-        const int32_t* it = a.items + (size_t)m * IT_WORDS;
-        if (it[IT_SLOT] >= 0) {  // a search without a work item this superstep leaves its row inert
-          pv = it[IT_PROW];      // state rows (page * 64 + offset), -1 = no parent
-          ov = it[IT_ROW];
-          rd = it[IT_RID];
-          tc = it[IT_TCODE];
-        }
-      } else {
-        pv = a.prev_idx[m];
-        ov = a.out_idx[m];
-        if (LAYER0) {
-          rd = a.rid[m];
-          tc = a.tcode[m];
-        }
+      pv = a.prev_idx[m];
+      ov = a.out_idx[m];
+      if (LAYER0) {
+        rd = a.rid[m];
+        tc = a.tcode[m];
       }
     }
     s_prev[tid] = pv;
@@ -175,6 +179,28 @@ __global__ __launch_bounds__(256, 2) void lstm_layer_kernel(LstmArgs a) {
     s_rid[tid] = rd;
     s_tc[tid] = tc;
   }
+  return true;
+}
+
+template <bool LAYER0>
+__global__ __launch_bounds__(256, 2) void lstm_layer_kernel(LstmArgs a) {
+  __shared__ TileLds tt[2];  // double-buffered k-tiles: one barrier per tile
+  __shared__ long long s_prev[BM];
+  __shared__ long long s_out[BM];
+  __shared__ int s_rid[BM];
+  __shared__ int s_tc[BM];
+  const int hp = a.hp;
+  const int ct_n = hp / 32;  // column tiles (32 hidden units each)
+  // XCD-aware decode: the ct_n column tiles of one row tile share bid % 8 (one XCD's L2 serves the A rows)
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, within = bid >> 3;
+  const int rowtile = (within / ct_n) * 8 + xcd;
+  const int coltile = within % ct_n;
+  if (!lstm_tile_rows<LAYER0>(a, rowtile, s_prev, s_out, s_rid, s_tc)) return;  // uniform over the workgroup
+#if TSG_ABLATE == 21
+  return;
+#endif
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   __syncthreads();
   const int K = LAYER0 ? hp : 2 * hp;
   const int ldw = 4 * hp;
@@ -284,7 +310,7 @@ __global__ __launch_bounds__(256, 2) void lstm_layer_kernel(LstmArgs a) {
     const float cp = s_prev[r] >= 0 ? cprev[i] : 0.0f;
     const float cn = tsg_sigmoid(zf) * cp + tsg_sigmoid(zi) * tsg_tanh(zg);
     const float hn = tsg_sigmoid(zo) * tsg_tanh(cn);
-    if (row0 + r >= n || s_out[r] < 0) continue;
+    if (s_out[r] < 0) continue;  // no row at this position of the tile
     const size_t o = (size_t)s_out[r] * hp + u;
 #if TSG_ABLATE >= 13
     if (cn == 12345.0f) a.c[o] = hn;
@@ -343,43 +369,14 @@ __global__ __launch_bounds__(256, 3) void lstm_layer_split_kernel(LstmArgs a) {
   __shared__ long long s_out[BM];
   __shared__ int s_rid[BM];
   __shared__ int s_tc[BM];
-  const int n = a.n_rows_dev ? *a.n_rows_dev : a.n_rows_host;
   const int hp = a.hp;
   const int ct_n = hp / 32;
   const int bid = blockIdx.x;
   const int xcd = bid & 7, within = bid >> 3;
   const int rowtile = (within / ct_n) * 8 + xcd;
   const int coltile = within % ct_n;
-  const int row0 = rowtile * BM;
-  if (row0 >= n) return;
+  if (!lstm_tile_rows<LAYER0>(a, rowtile, s_prev, s_out, s_rid, s_tc)) return;  // uniform over the workgroup
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  if (tid < BM) {
-    const int m = row0 + tid;
-    long long pv = -1, ov = -1;
-    int rd = 0, tc = 0;
-    if (m < n) {
-      if (a.items) {
-        const int32_t* it = a.items + (size_t)m * IT_WORDS;
-        if (it[IT_SLOT] >= 0) {
-          pv = it[IT_PROW];
-          ov = it[IT_ROW];
-          rd = it[IT_RID];
-          tc = it[IT_TCODE];
-        }
-      } else {
-        pv = a.prev_idx[m];
-        ov = a.out_idx[m];
-        if (LAYER0) {
-          rd = a.rid[m];
-          tc = a.tcode[m];
-        }
-      }
-    }
-    s_prev[tid] = pv;
-    s_out[tid] = ov;
-    s_rid[tid] = rd;
-    s_tc[tid] = tc;
-  }
   __syncthreads();
   const int K = LAYER0 ? hp : 2 * hp;
   const int nkt = K / BK;
@@ -505,7 +502,7 @@ __global__ __launch_bounds__(256, 3) void lstm_layer_split_kernel(LstmArgs a) {
     const float cp = s_prev[r] >= 0 ? cprev[i] : 0.0f;
     const float cn = tsg_sigmoid(zf) * cp + tsg_sigmoid(zi) * tsg_tanh(zg);
     const float hn = tsg_sigmoid(zo) * tsg_tanh(cn);
-    if (row0 + r >= n || s_out[r] < 0) continue;
+    if (s_out[r] < 0) continue;  // no row at this position of the tile
     const size_t o = (size_t)s_out[r] * hp + u;
     a.c[o] = cn;
     hs_out[o] = tsg_split_word(hn);
@@ -521,7 +518,7 @@ static int check_model_dims(const tsg_model* m) {
 
 int tsg_launch_lstm_layer(const tsg_model* m, int layer, int max_rows, const int32_t* n_rows_dev, int n_rows_host,
                           const int64_t* prev_idx, const int64_t* out_idx, const int32_t* rid, const int32_t* tcode,
-                          const int32_t* items, int exp_cap, const float* h_below, float* h, float* c,
+                          const tsg_engine* eng, const float* h_below, float* h, float* c,
                           hipStream_t stream, int split) {
   LstmArgs a;
   a.layer = layer;
@@ -532,8 +529,11 @@ int tsg_launch_lstm_layer(const tsg_model* m, int layer, int max_rows, const int
   a.out_idx = out_idx;
   a.rid = rid;
   a.tcode = tcode;
-  a.items = items;
-  a.exp_cap = exp_cap;
+  a.items = eng ? eng->items : nullptr;
+  a.item_counts = eng ? eng->item_counts : nullptr;
+  a.pc = eng ? eng->counters : nullptr;
+  a.slots = eng ? eng->slots : 0;
+  if (eng) max_rows = (int)tsg_item_positions(eng->slots);  // row tiles of every region of the work list
   a.h_below = h_below;
   a.h = h;
   a.c = c;
@@ -568,5 +568,5 @@ extern "C" int tsg_lstm_step_batched(const tsg_model* m, const tsg_lstm_step* s,
   if (!s->prev_idx || !s->out_idx) return TSG_E_INVALID;
   if (s->layer == 0 && (!s->rid || !s->tcode)) return TSG_E_INVALID;
   return tsg_launch_lstm_layer(m, s->layer, s->n_rows_host, s->n_rows_dev, s->n_rows_host, s->prev_idx, s->out_idx,
-                               s->rid, s->tcode, nullptr, 0, s->h_below, s->h, s->c, (hipStream_t)stream, 0);
+                               s->rid, s->tcode, nullptr, s->h_below, s->h, s->c, (hipStream_t)stream, 0);
 }

@@ -10,7 +10,7 @@
 
 int tsg_launch_lstm_layer(const tsg_model* m, int layer, int max_rows, const int32_t* n_rows_dev, int n_rows_host,
                           const int64_t* prev_idx, const int64_t* out_idx, const int32_t* rid, const int32_t* tcode,
-                          const int32_t* items, int exp_cap, const float* h_below, float* h, float* c,
+                          const tsg_engine* eng, const float* h_below, float* h, float* c,
                           hipStream_t stream, int split);
 
 // =====================================================================================
@@ -154,6 +154,16 @@ __device__ __forceinline__ void engine_control_block(const EngineDev& D) {  // a
   const int p = D.e.page_flags[threadIdx.x * 32] == stamp;
   const int w = D.e.page_flags[TSG_FLAG_PLANE + threadIdx.x * 32] == stamp;
   const int any_p = __syncthreads_or(p), any_w = __syncthreads_or(w);
+  // work list: the frontier kernel filled (and published, PC_ITEM_PLANE) the plane of counters that the other
+  // kernels of this superstep read; the other plane is cleared here for the next frontier launch
+  const int ss = D.e.counters[PC_SUPERSTEP];
+  const int nreg = tsg_n_regions(D.e.slots);
+  for (int r = threadIdx.x; r < nreg; r += blockDim.x) {
+    int32_t* c = D.e.item_counts + tsg_item_cnt_index(D.e.slots, (ss + 1) & 1, r);
+    c[0] = 0;
+    c[1] = 0;
+  }
+  __syncthreads();
   if (threadIdx.x == 0) engine_control_step(D, any_p != 0, any_w != 0);
 }
 
@@ -176,11 +186,15 @@ __global__ __launch_bounds__(256) void cand_dis_kernel(EngineDev D, int superste
   const int md = D.g.max_degree;
   const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (blockIdx.x == 0 && D.od.n_od > 0) engine_control_block(D);  // engine run (not the stand-alone scoring entry)
-  const int idx = (int)(t / md), c = (int)(t % md);
-  if (idx >= D.e.slots) return;
-  const int32_t* it = D.e.items + (size_t)idx * IT_WORDS;  // items are indexed by slot
+  const long q = t / md;  // position in the work list
+  const int c = (int)(t % md);
+  const int region = (int)(q / TSG_REGION_SLOTS), pos = (int)(q % TSG_REGION_SLOTS);
+  if (region >= tsg_n_regions(D.e.slots)) return;
+  const int32_t* it = D.e.items + (size_t)q * IT_WORDS;
   const int ncand = it[IT_NCAND];
-  if (it[IT_SLOT] < 0 || ncand < 2 || c >= ncand) return;
+  int n_long, n_short;
+  tsg_item_counts(D.e.item_counts, D.e.counters, D.e.slots, region, n_long, n_short);
+  if (!tsg_item_filled(pos, tsg_region_size(D.e.slots, region), n_long, n_short) || ncand < 2 || c >= ncand) return;
   const int cand = D.g.indices[D.g.indptr[it[IT_RID]] + c];
   float dis;
   if (D.g.dist_table) {  // region graphs: region_dist[c][des] / 100 (search.py:1049)
@@ -199,16 +213,23 @@ __global__ __launch_bounds__(256) void cand_dis_kernel(EngineDev D, int superste
 // loads.  Chains longer than 64 hop through anc[.][63] once per 64 rows.
 template <int JT, bool SPLIT>
 __global__ __launch_bounds__(256) void score_frontier_kernel(tsg_model m, EngineDev D, int superstep) {
-  const int idx = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  // wave w of the launch -> position w / R of region w % R of the work list: the fronts of all regions (long
+  // ancestor chains) start first, the empty middle exits at once, the short chains fill in behind
+  const int w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
-  if (idx >= D.e.slots) return;
-  const int32_t* it = D.e.items + (size_t)idx * IT_WORDS;  // items are indexed by slot
-  if (it[IT_SLOT] < 0) return;                               // this search emitted nothing (finished batch)
+  const int nreg = tsg_n_regions(D.e.slots);
+  const int region = w % nreg, pos = w / nreg;
+  const int rs = tsg_region_size(D.e.slots, region);
+  if (pos >= rs) return;
+  const int32_t* it = D.e.items + ((size_t)region * TSG_REGION_SLOTS + pos) * IT_WORDS;
+  int n_long, n_short;
+  tsg_item_counts(D.e.item_counts, D.e.counters, D.e.slots, region, n_long, n_short);
   const int ncand = it[IT_NCAND];
   const int b = it[IT_SLOT], e = it[IT_ROW];  // e: the state row of the expanded node
   constexpr int LV = TSG_UP_LEVELS;  // = 64 ancestors per row
   int32_t* anc = D.e.exp_up;
   const int parent = it[IT_PROW];
+  if (!tsg_item_filled(pos, rs, n_long, n_short)) return;  // not filled in this superstep (the words above are stale)
   // lane i: the state row of the (i+1)-th ancestor; kept in a register (this wave must not read back its own store)
   int mine = lane == 0 ? parent : (parent >= 0 ? anc[(size_t)parent * LV + lane - 1] : -1);
   anc[(size_t)e * LV + lane] = mine;
@@ -282,13 +303,13 @@ __global__ __launch_bounds__(256) void score_frontier_kernel(tsg_model m, Engine
 }
 
 static void launch_cand_dis(const EngineDev& D, int superstep, hipStream_t s) {
-  const long threads = (long)D.e.slots * D.g.max_degree;
+  const long threads = (long)tsg_item_positions(D.e.slots) * D.g.max_degree;
   hipLaunchKernelGGL(cand_dis_kernel, dim3(tsg_cdiv(threads, 256)), dim3(256), 0, s, D, superstep);
 }
 
 template <bool SPLIT>
 static void launch_score_frontier_t(const tsg_model* m, const EngineDev& D, int superstep, hipStream_t s) {
-  const dim3 grid(tsg_cdiv(D.e.slots, TSG_SCORE_WPB)), blk(64 * TSG_SCORE_WPB);
+  const dim3 grid(tsg_cdiv(tsg_n_regions(D.e.slots) * TSG_REGION_SLOTS, TSG_SCORE_WPB)), blk(64 * TSG_SCORE_WPB);
   switch (jt_for(m->hp)) {
     case 1: hipLaunchKernelGGL((score_frontier_kernel<1, SPLIT>), grid, blk, 0, s, *m, D, superstep); break;
     case 2: hipLaunchKernelGGL((score_frontier_kernel<2, SPLIT>), grid, blk, 0, s, *m, D, superstep); break;
@@ -453,15 +474,19 @@ __device__ __forceinline__ HeapEnt heap_pop(uint64_t* h, int& n, const int32_t* 
 #ifndef TSG_SPW
 #define TSG_SPW 8
 #endif
+static_assert(TSG_REGION_SLOTS % TSG_SPW == 0, "the searches of a wave share one region of the work list");
 __global__ __launch_bounds__(256) void frontier_kernel(EngineDev D, int superstep) {
   const int b = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * TSG_SPW + (threadIdx.x & 63);
   if (b >= D.e.slots || (threadIdx.x & 63) >= TSG_SPW) return;
+  // the plane of item_counts this launch fills (superstep parity), for the kernels that follow; nothing reads
+  // the word during this launch
+  if (b == 0) D.e.counters[PC_ITEM_PLANE] = D.e.counters[PC_SUPERSTEP] & 1;
   int32_t* S = D.e.slot_state + (size_t)b * SS_WORDS;
   int phase = S[SS_PHASE];
   if (phase == PH_DONE) return;
   const tsg_graph& g = D.g;
   const tsg_od_batch& od = D.od;
-  int32_t* my_item = D.e.items + (size_t)b * IT_WORDS;  // one work item per search and superstep, indexed by slot
+  int32_t itw[IT_WORDS] = {0};  // the work item of this superstep, if one is emitted: written to the work list at the end
   int32_t* shared = D.e.shared_counters;  // OD queue + completion, common to all sub-engines of a batch
   uint64_t* heap = D.e.heap + (size_t)b * D.e.heap_cap;
   uint32_t* table = D.e.table + (size_t)b * g.n_roads;
@@ -525,7 +550,6 @@ __global__ __launch_bounds__(256) void frontier_kernel(EngineDev D, int superste
       atomicAdd(&pc[PC_ABORTS], 1);
       phase = PH_IDLE;
     }
-    my_item[IT_SLOT] = -1;
   };
 
 #if TSG_STAMP
@@ -637,12 +661,12 @@ __global__ __launch_bounds__(256) void frontier_kernel(EngineDev D, int superste
   CKPT(0);
   STAMP_ADD(7, 1);
   bool emitted = false;
+  int item_depth = 0;
   int pops_here = 0;
   while (!emitted && !err) {
     if (phase == PH_IDLE) {
       if (gen >= TSG_GEN_MAX) {  // table generation space exhausted for this slot: stop refilling it
         phase = PH_DONE;
-        my_item[IT_SLOT] = -1;
         break;
       }
       // admission: closed while the page pool is short; the first search of slot b waits for its place on the
@@ -661,10 +685,7 @@ __global__ __launch_bounds__(256) void frontier_kernel(EngineDev D, int superste
           if (i < od.n_od) take = i;
         }
       }
-      if (take < 0) {  // nothing to start now: stay idle (sent-back OD pairs may still arrive)
-        my_item[IT_SLOT] = -1;
-        break;
-      }
+      if (take < 0) break;  // nothing to start now: stay idle (sent-back OD pairs may still arrive)
       odi = take;
       // ---- start a new search (search.py:255-278)
       ++gen;
@@ -713,7 +734,7 @@ __global__ __launch_bounds__(256) void frontier_kernel(EngineDev D, int superste
         break;
       }
       const int k = warm_k++;
-      int32_t* it = my_item;
+      int32_t* it = itw;
       it[IT_SLOT] = b;
       it[IT_ROW] = my_pages[k >> TSG_PAGE_SHIFT] * TSG_PAGE_ROWS + (k & (TSG_PAGE_ROWS - 1));
       it[IT_PROW] = k > 0 ? my_pages[(k - 1) >> TSG_PAGE_SHIFT] * TSG_PAGE_ROWS + ((k - 1) & (TSG_PAGE_ROWS - 1)) : -1;
@@ -723,6 +744,7 @@ __global__ __launch_bounds__(256) void frontier_kernel(EngineDev D, int superste
       it[IT_DES] = des;
       it[IT_LP] = 0;
       it[IT_DEPTH] = k + 1;
+      item_depth = k + 1;
       st_items += 1;
       D.e.page_flags[(b & 255) * 32] = ss_stamp;
       if (warm_k >= plen - 1) phase = PH_SEARCH;
@@ -848,7 +870,7 @@ __global__ __launch_bounds__(256) void frontier_kernel(EngineDev D, int superste
         st_cand += C;
         st_chain += depth;
       }
-      int32_t* it = my_item;
+      int32_t* it = itw;
       it[IT_SLOT] = b;
       it[IT_ROW] = row_page * TSG_PAGE_ROWS + (e & (TSG_PAGE_ROWS - 1));
       st_items += 1;
@@ -859,6 +881,7 @@ __global__ __launch_bounds__(256) void frontier_kernel(EngineDev D, int superste
       it[IT_DES] = des;
       it[IT_LP] = nd[ND_LP];
       it[IT_DEPTH] = depth;
+      item_depth = C > 1 ? depth : 0;  // single-successor expansions are not scored: short
       D.e.page_flags[(b & 255) * 32] = ss_stamp;
       phase = PH_EXPANDED;
       emitted = true;
@@ -866,10 +889,7 @@ __global__ __launch_bounds__(256) void frontier_kernel(EngineDev D, int superste
       break;
     }
     if (emitted || err) break;
-    if (yielded) {
-      my_item[IT_SLOT] = -1;
-      break;
-    }
+    if (yielded) break;
     CKPT(10);
     // ---- the search is over (search.py:421-424): destination popped, queue empty, or budget spent
     if (fin_status < 0) {
@@ -922,7 +942,6 @@ __global__ __launch_bounds__(256) void frontier_kernel(EngineDev D, int superste
   if (err) {
     // a workspace cap was hit: report, finish the OD as OVERFLOW so that the batch still terminates
     atomicExch(&shared[CT_ERROR], 1);
-    my_item[IT_SLOT] = -1;
     if (odi >= 0 && odi < od.n_od) {
       od.out_len[odi] = 0;
       od.out_status[odi] = TSG_STATUS_OVERFLOW;
@@ -931,6 +950,37 @@ __global__ __launch_bounds__(256) void frontier_kernel(EngineDev D, int superste
     }
     release_pages();
     phase = PH_IDLE;
+  }
+  // ---- work list of the superstep (tsg_common.h): the wave's emitting searches take their positions with one
+  // atomic per class; the lanes have reconverged here (a wave that has not is still correct: every group of
+  // lanes then runs this block for itself)
+  {
+    const bool emit = emitted && !err;
+    const bool is_long = emit && item_depth >= TSG_LONG_DEPTH;
+    const unsigned long long m_long = __ballot(is_long), m_short = __ballot(emit && !is_long);
+    const unsigned long long m_any = m_long | m_short;
+    if (m_any) {
+      const int lane = threadIdx.x & 63;
+      const int leader = __ffsll((long long)m_any) - 1;
+      const int region = b / TSG_REGION_SLOTS;  // TSG_REGION_SLOTS is a multiple of TSG_SPW: one region per wave
+      int base_l = 0, base_s = 0;
+      if (lane == leader) {
+        int32_t* oc = D.e.item_counts + tsg_item_cnt_index(D.e.slots, (ss_stamp - 1) & 1, region);
+        if (m_long) base_l = atomicAdd(&oc[0], __popcll(m_long));
+        if (m_short) base_s = atomicAdd(&oc[1], __popcll(m_short));
+      }
+      base_l = __shfl(base_l, leader, TSG_WAVE);
+      base_s = __shfl(base_s, leader, TSG_WAVE);
+      if (emit) {
+        const unsigned long long below = (1ull << lane) - 1ull;
+        const int p = is_long ? base_l + __popcll(m_long & below)
+                              : tsg_region_size(D.e.slots, region) - 1 - (base_s + __popcll(m_short & below));
+        int4* dst = reinterpret_cast<int4*>(D.e.items + ((size_t)region * TSG_REGION_SLOTS + p) * IT_WORDS);
+        dst[0] = make_int4(itw[0], itw[1], itw[2], itw[3]);
+        dst[1] = make_int4(itw[4], itw[5], itw[6], itw[7]);
+        dst[2] = make_int4(itw[8], 0, 0, 0);
+      }
+    }
   }
   CKPT(2);
 #if TSG_STAMP
@@ -983,7 +1033,7 @@ static int check_engine(const tsg_model* m, const tsg_graph* g, const tsg_od_bat
   if (!e->table || e->table_bytes < B * (size_t)g->n_roads * 4) return TSG_E_TOO_SMALL;
   if (!e->nodes || e->nodes_bytes < B * e->node_cap * ND_WORDS * 4) return TSG_E_TOO_SMALL;
   if (!e->exp_meta || e->exp_meta_bytes < B * e->exp_cap * EM_WORDS * 4) return TSG_E_TOO_SMALL;
-  if (!e->items || e->items_bytes < B * IT_WORDS * 4) return TSG_E_TOO_SMALL;
+  if (!e->items || e->items_bytes < tsg_item_positions(e->slots) * IT_WORDS * 4) return TSG_E_TOO_SMALL;
   if (!e->cand_lp || e->cand_lp_bytes < B * (size_t)g->max_degree * 4) return TSG_E_TOO_SMALL;
   if (!e->counters || e->counters_bytes < PC_WORDS * 4) return TSG_E_TOO_SMALL;
   if (!e->shared_counters || e->shared_counters == e->counters) return TSG_E_INVALID;
@@ -994,6 +1044,7 @@ static int check_engine(const tsg_model* m, const tsg_graph* g, const tsg_od_bat
   if (!e->page_ring || e->page_ring_bytes < (size_t)e->n_pages * 4) return TSG_E_TOO_SMALL;
   if (!e->retry || e->retry_bytes < B * 4) return TSG_E_TOO_SMALL;
   if (!e->page_flags || e->page_flags_bytes < 2 * TSG_FLAG_PLANE * 4) return TSG_E_TOO_SMALL;
+  if (!e->item_counts || e->item_counts_bytes < tsg_item_count_words(e->slots) * 4) return TSG_E_TOO_SMALL;
   if (m) {
     if (m->hp <= 0 || (m->hp % 64) != 0 || m->hp > 512) return TSG_E_INVALID;
     if (m->n_layers < 1 || m->n_layers > TSG_MAX_LAYERS) return TSG_E_INVALID;
@@ -1031,6 +1082,8 @@ extern "C" int tsg_engine_reset(const tsg_engine* e, const tsg_graph* g, void* s
   TSG_HIP_TRY(hipMemsetAsync(e->slot_state, 0, (size_t)e->slots * SS_WORDS * 4, s));  // phase IDLE, gen 0
   TSG_HIP_TRY(hipMemsetAsync(e->table, 0, (size_t)e->slots * g->n_roads * 4, s));
   TSG_HIP_TRY(hipMemsetAsync(e->page_flags, 0, 2 * TSG_FLAG_PLANE * 4, s));
+  TSG_HIP_TRY(hipMemsetAsync(e->items, 0, tsg_item_positions(e->slots) * IT_WORDS * 4, s));
+  TSG_HIP_TRY(hipMemsetAsync(e->item_counts, 0, tsg_item_count_words(e->slots) * 4, s));
   hipLaunchKernelGGL(engine_init_pages_kernel, dim3(tsg_cdiv(e->n_pages, 256)), dim3(256), 0, s, *e);
   TSG_LAUNCH_CHECK();
   return 0;
@@ -1085,7 +1138,7 @@ extern "C" int tsg_engine_run(const tsg_model* m, const tsg_graph* g, const tsg_
     launch_cand_dis(D, ss, s);
     TSG_LAUNCH_CHECK();
     for (int l = 0; l < m->n_layers; ++l) {
-      rc = tsg_launch_lstm_layer(m, l, e->slots, nullptr, e->slots, nullptr, nullptr, nullptr, nullptr, e->items, e->exp_cap,
+      rc = tsg_launch_lstm_layer(m, l, e->slots, nullptr, e->slots, nullptr, nullptr, nullptr, nullptr, e,
                                  l > 0 ? e->h[l - 1] : nullptr, e->h[l], e->c[l], s, e->state_format);
       if (rc) return rc;
     }
@@ -1170,7 +1223,7 @@ extern "C" int tsg_engine_run_profiled(const tsg_model* m, const tsg_graph* g, c
     (void)hipEventRecord(ev[q++], s);
     for (int l = 0; l < m->n_layers && rc == 0; ++l) {
       (void)hipEventRecord(ev[q++], s);
-      rc = tsg_launch_lstm_layer(m, l, e->slots, nullptr, e->slots, nullptr, nullptr, nullptr, nullptr, e->items, e->exp_cap,
+      rc = tsg_launch_lstm_layer(m, l, e->slots, nullptr, e->slots, nullptr, nullptr, nullptr, nullptr, e,
                                  l > 0 ? e->h[l - 1] : nullptr, e->h[l], e->c[l], s, e->state_format);
       (void)hipEventRecord(ev[q++], s);
     }

@@ -371,12 +371,14 @@ class AStarEngine(object):
         self.page_ring = torch.empty(self.n_pages, dtype=i32, device=dev)
         self.retry = None       # sized per OD batch in run()
         self.page_flags = torch.zeros((2, 256, 32), dtype=i32, device=dev)
-        self.items = torch.empty((B, 12), dtype=i32, device=dev)
+        nreg = (B + 4095) // 4096                   # TSG_REGION_SLOTS: the work list is kept per region of slots
+        self.items = torch.zeros((nreg * 4096, 12), dtype=i32, device=dev)
+        self.item_counts = torch.zeros((2, nreg, 32), dtype=i32, device=dev)
         self.cand_lp = torch.empty((B, graph.max_degree), dtype=f32, device=dev)
         self.counters = torch.zeros((2, 16), dtype=i32, device=dev)   # row 0: page control, row 1: OD queue / totals
         e = _lib.Engine()
         e.slots, e.exp_cap, e.node_cap, e.heap_cap = B, self.exp_cap, self.node_cap, self.heap_cap
-        for name in ('slot_state', 'heap', 'table', 'nodes', 'exp_meta', 'exp_up', 'items', 'cand_lp', 'slot_pages',
+        for name in ('slot_state', 'heap', 'table', 'nodes', 'exp_meta', 'exp_up', 'items', 'item_counts', 'cand_lp', 'slot_pages',
                      'page_ring', 'page_flags'):
             t = getattr(self, name)
             setattr(e, name, t.data_ptr())
