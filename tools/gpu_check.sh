@@ -10,7 +10,7 @@ tail -1 gpurun_out/smoke.log
 timeout -k 10 400 python -u bench.py > gpurun_out/bench.log 2>&1 || { tail -30 gpurun_out/bench.log; exit 1; }
 tail -1 gpurun_out/bench.log
 rm -rf gpurun_out/prof
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -- python3 bench.py --ods 16384 --warmup 0 --cpu-seconds 0 > gpurun_out/bench_prof.log 2>&1 || { tail -30 gpurun_out/bench_prof.log; exit 1; }
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -- python3 bench.py --warmup 0 --cpu-seconds 0 > gpurun_out/bench_prof.log 2>&1 || { tail -30 gpurun_out/bench_prof.log; exit 1; }
 tail -1 gpurun_out/bench_prof.log
 find gpurun_out/prof -name '*kernel_stats.csv' | head
 # the full kernel trace is large: keep only the stats

@@ -5,7 +5,7 @@ set -o pipefail
 tag=${1:-prof}
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-BENCH="bench.py --ods 16384 --warmup 0 --cpu-seconds 0"
+BENCH="bench.py --warmup 0 --cpu-seconds 0"   # the default workload and timed step of the bench line, without the warm-up step (its small launches would enter the per-kernel averages) and the CPU baseline
 rm -rf gpurun_out/${tag}_stats gpurun_out/${tag}_pmc_fetch gpurun_out/${tag}_pmc_write
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_stats -- python3 $BENCH > gpurun_out/${tag}_bench_stats.log 2>&1 || { tail -20 gpurun_out/${tag}_bench_stats.log; exit 1; }
 find gpurun_out/${tag}_stats -name '*kernel_trace.csv' -delete

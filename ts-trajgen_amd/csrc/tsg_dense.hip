@@ -12,7 +12,9 @@
 #include "tsg_common.h"
 
 #ifndef TSG_ABLATE
+#ifndef TSG_ABLATE
 #define TSG_ABLATE 0  // timing-only ablation builds; 0 in the shipped library
+#endif
 #endif
 
 #define BM 128
@@ -362,8 +364,39 @@ __device__ __forceinline__ unsigned tsg_split_word(float x) {
   return (unsigned)__builtin_bit_cast(unsigned short, mj) | ((unsigned)__builtin_bit_cast(unsigned short, mn) << 16);
 }
 
+#ifndef TSG_LSTM_STAMP
+#define TSG_LSTM_STAMP 0  // diagnostic build only: where a wave of the recurrence spends its time (never shipped)
+#endif
+#if TSG_LSTM_STAMP
+// [layer0 ? 0 : 1][workgroup % 64][phase]: sums of 10-ns ticks over waves (0 work items, 1 prologue, 2 k loop,
+// 3 unused, 4 epilogue), [7] = waves.  Kept per wave in registers and added once at the end, spread over 64 lines:
+// five same-address atomics per wave halved the whole engine's throughput.
+__device__ unsigned long long g_lstm_stamp[2][64][8];
+extern "C" int tsg_debug_read_lstm_stamps(unsigned long long* out_host, int reset) {
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  if (hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_lstm_stamp), sizeof(g_lstm_stamp)) != hipSuccess) return -1;
+  if (reset) {
+    static unsigned long long z[2 * 64 * 8] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_lstm_stamp), z, sizeof(z)) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#define LSTAMP(i)                          \
+  {                                        \
+    const long long now_ = wall_clock64(); \
+    lacc_[i] = now_ - lst_;                \
+    lst_ = now_;                           \
+  }
+#else
+#define LSTAMP(i)
+#endif
+
 template <bool LAYER0>
 __global__ __launch_bounds__(256, 3) void lstm_layer_split_kernel(LstmArgs a) {
+#if TSG_LSTM_STAMP
+  long long lst_ = wall_clock64();
+  long long lacc_[5] = {0, 0, 0, 0, 0};
+#endif
   __shared__ TileB16 tb[2];
   __shared__ long long s_prev[BM];
   __shared__ long long s_out[BM];
@@ -378,6 +411,7 @@ __global__ __launch_bounds__(256, 3) void lstm_layer_split_kernel(LstmArgs a) {
   if (!lstm_tile_rows<LAYER0>(a, rowtile, s_prev, s_out, s_rid, s_tc)) return;  // uniform over the workgroup
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   __syncthreads();
+  LSTAMP(0)
   const int K = LAYER0 ? hp : 2 * hp;
   const int nkt = K / BK;
   const int ldw = 4 * hp;
@@ -413,6 +447,13 @@ __global__ __launch_bounds__(256, 3) void lstm_layer_split_kernel(LstmArgs a) {
   const long long my_prev = s_prev[wave * 32 + lr], my_out = s_out[wave * 32 + lr];
   const unsigned* hs_own = reinterpret_cast<const unsigned*>(a.h);
   const unsigned* hs_below = reinterpret_cast<const unsigned*>(a.h_below);
+  long long ab_prev[4] = {0, 0, 0, 0}, ab_out[4] = {0, 0, 0, 0};  // TSG_ABLATE 37 only
+  if (TSG_ABLATE == 37) {
+    for (int j_ = 0; j_ < 4; ++j_) {
+      ab_prev[j_] = s_prev[wave * 32 + (lane >> 3) + 8 * j_];
+      ab_out[j_] = s_out[wave * 32 + (lane >> 3) + 8 * j_];
+    }
+  }
   const _Float16* wimg = reinterpret_cast<const _Float16*>(a.wt) + (size_t)coltile * nkt * (2 * BN * BK);
   // prefetch registers: the gathered state rows (HBM latency) run two k-tiles ahead, the weights (L2) one
   tsg_u4 na0, na1, na2, na3, ma0, ma1, ma2, ma3, nb0, nb1, nb2, nb3;
@@ -427,6 +468,14 @@ __global__ __launch_bounds__(256, 3) void lstm_layer_split_kernel(LstmArgs a) {
     MASK = ridx_ >= 0 ? 0xffffffffu : 0u;                                                                    \
     const tsg_u4* s4_ = reinterpret_cast<const tsg_u4*>(src_);                                               \
     R0 = s4_[0]; R1 = s4_[1]; R2 = s4_[2]; R3 = s4_[3];                                                      \
+    if (TSG_ABLATE == 37) { /* timing only (wrong operands): the same bytes with four lanes per 64-byte run */ \
+      const unsigned* b_ = (below_ ? hs_below : hs_own) + ((below_ || LAYER0) ? k0_ : k0_ - hp) + 4 * (lane & 7); \
+      const long long* rr_ = below_ ? ab_out : ab_prev;                                                      \
+      R0 = *reinterpret_cast<const tsg_u4*>(b_ + (size_t)(rr_[0] >= 0 ? rr_[0] : 0) * hp);                   \
+      R1 = *reinterpret_cast<const tsg_u4*>(b_ + (size_t)(rr_[1] >= 0 ? rr_[1] : 0) * hp);                   \
+      R2 = *reinterpret_cast<const tsg_u4*>(b_ + (size_t)(rr_[2] >= 0 ? rr_[2] : 0) * hp);                   \
+      R3 = *reinterpret_cast<const tsg_u4*>(b_ + (size_t)(rr_[3] >= 0 ? rr_[3] : 0) * hp);                   \
+    }                                                                                                        \
   }
   auto gload_w = [&](int kt) {
     const tsg_u4* w4 = reinterpret_cast<const tsg_u4*>(wimg + (size_t)kt * (2 * BN * BK) + (size_t)tid * 32);
@@ -443,6 +492,7 @@ __global__ __launch_bounds__(256, 3) void lstm_layer_split_kernel(LstmArgs a) {
   lstore(0);
   tsg_u4 ca0 = na0 & amask_n, ca1 = na1 & amask_n, ca2 = na2 & amask_n, ca3 = na3 & amask_n;
   __syncthreads();
+  LSTAMP(1)
   const tsg_h8 scale = {(_Float16)2048.0f, (_Float16)2048.0f, (_Float16)2048.0f, (_Float16)2048.0f,
                         (_Float16)2048.0f, (_Float16)2048.0f, (_Float16)2048.0f, (_Float16)2048.0f};
   for (int kt = 0, cur = 0; kt < nkt; ++kt, cur ^= 1) {
@@ -477,6 +527,7 @@ __global__ __launch_bounds__(256, 3) void lstm_layer_split_kernel(LstmArgs a) {
     }
     __syncthreads();
   }
+  LSTAMP(2)
   float4 tq[4];
   auto tload = [&](int i) {
     const int r = wave * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
@@ -507,6 +558,14 @@ __global__ __launch_bounds__(256, 3) void lstm_layer_split_kernel(LstmArgs a) {
     a.c[o] = cn;
     hs_out[o] = tsg_split_word(hn);
   }
+  LSTAMP(4)
+#if TSG_LSTM_STAMP
+  if ((threadIdx.x & 63) == 0) {
+    unsigned long long* g_ = g_lstm_stamp[LAYER0 ? 0 : 1][blockIdx.x & 63];
+    for (int i = 0; i < 5; ++i) atomicAdd(&g_[i], (unsigned long long)lacc_[i]);
+    atomicAdd(&g_[7], 1ull);
+  }
+#endif
 }
 
 static int check_model_dims(const tsg_model* m) {
