@@ -135,9 +135,9 @@ struct LstmArgs {
 // tile is a stretch of 128 positions of one region of the work list (tsg_common.h); returns false when none of
 // them is filled in this superstep.  Fills s_prev / s_out (-1 = no row) and, for layer 0, s_rid / s_tc.
 static_assert(TSG_REGION_SLOTS % BM == 0, "whole row tiles per region of the work list");
-template <bool LAYER0>
-__device__ __forceinline__ bool lstm_tile_rows(const LstmArgs& a, int rowtile, long long* s_prev, long long* s_out,
-                                               int* s_rid, int* s_tc) {
+template <bool LAYER0, typename IDX>
+__device__ __forceinline__ bool lstm_tile_rows(const LstmArgs& a, int rowtile, IDX* s_prev, IDX* s_out, int* s_rid,
+                                               int* s_tc) {
   const int tid = threadIdx.x;
   if (a.items) {
     constexpr int TPR = TSG_REGION_SLOTS / BM;
@@ -154,8 +154,8 @@ __device__ __forceinline__ bool lstm_tile_rows(const LstmArgs& a, int rowtile, l
     if (!(p0 < n_long || (n_short > 0 && p0 < rs && p0 + BM > rs - n_short))) return false;  // nothing filled here
     if (tid < BM) {
       const bool filled = tsg_item_filled(p, rs, n_long, n_short);
-      s_prev[tid] = filled ? (long long)w0.z : -1;  // state rows (page * 64 + offset), -1 = no parent
-      s_out[tid] = filled ? (long long)w0.y : -1;
+      s_prev[tid] = filled ? (IDX)w0.z : (IDX)-1;  // state rows (page * 64 + offset), -1 = no parent
+      s_out[tid] = filled ? (IDX)w0.y : (IDX)-1;
       s_rid[tid] = filled ? w0.w : 0;
       s_tc[tid] = filled ? w_tc : 0;
     }
@@ -176,8 +176,8 @@ __device__ __forceinline__ bool lstm_tile_rows(const LstmArgs& a, int rowtile, l
         tc = a.tcode[m];
       }
     }
-    s_prev[tid] = pv;
-    s_out[tid] = ov;
+    s_prev[tid] = (IDX)pv;
+    s_out[tid] = (IDX)ov;
     s_rid[tid] = rd;
     s_tc[tid] = tc;
   }
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256, 2) void lstm_layer_kernel(LstmArgs a) {
   const int xcd = bid & 7, within = bid >> 3;
   const int rowtile = (within / ct_n) * 8 + xcd;
   const int coltile = within % ct_n;
-  if (!lstm_tile_rows<LAYER0>(a, rowtile, s_prev, s_out, s_rid, s_tc)) return;  // uniform over the workgroup
+  if (!lstm_tile_rows<LAYER0, long long>(a, rowtile, s_prev, s_out, s_rid, s_tc)) return;  // uniform over the workgroup
 #if TSG_ABLATE == 21
   return;
 #endif
@@ -339,11 +339,12 @@ __global__ __launch_bounds__(256, 2) void lstm_layer_kernel(LstmArgs a) {
 typedef _Float16 tsg_h8 __attribute__((ext_vector_type(8)));
 typedef unsigned tsg_u4 __attribute__((ext_vector_type(4)));
 
-#define SB_LD 40  // f16 per LDS row: 64 B of data + 16 B pad -> conflict-free ds_read_b128 over 32 columns
-
+// One k-tile of the weights in LDS: [major|minor][128 columns][32 k] f16, 64 bytes per column, no padding: the
+// four 16-byte chunks of column c sit at chunk ^ ((c >> 2) & 3), which makes both the stores (one column per
+// thread) and the fragment reads (ds_read_b128, 32 columns per half wave) conflict-free.
 struct __align__(16) TileB16 {
-  _Float16 major[BN][SB_LD];
-  _Float16 minor[BN][SB_LD];
+  _Float16 major[BN][32];
+  _Float16 minor[BN][32];
 };
 
 __device__ __forceinline__ tsg_h8 tsg_pack_halves(unsigned w0, unsigned w1, unsigned w2, unsigned w3, unsigned w4,
@@ -398,8 +399,11 @@ __global__ __launch_bounds__(256, 3) void lstm_layer_split_kernel(LstmArgs a) {
   long long lacc_[5] = {0, 0, 0, 0, 0};
 #endif
   __shared__ TileB16 tb[2];
-  __shared__ long long s_prev[BM];
-  __shared__ long long s_out[BM];
+  // per wave: the gathered state rows of one k-tile, [32 rows][32 words]; the eight 16-byte pieces of row r sit
+  // at piece ^ (r & 7)
+  __shared__ __align__(16) unsigned s_a[4][32 * 32];
+  __shared__ int s_prev[BM];
+  __shared__ int s_out[BM];
   __shared__ int s_rid[BM];
   __shared__ int s_tc[BM];
   const int hp = a.hp;
@@ -408,7 +412,7 @@ __global__ __launch_bounds__(256, 3) void lstm_layer_split_kernel(LstmArgs a) {
   const int xcd = bid & 7, within = bid >> 3;
   const int rowtile = (within / ct_n) * 8 + xcd;
   const int coltile = within % ct_n;
-  if (!lstm_tile_rows<LAYER0>(a, rowtile, s_prev, s_out, s_rid, s_tc)) return;  // uniform over the workgroup
+  if (!lstm_tile_rows<LAYER0, int>(a, rowtile, s_prev, s_out, s_rid, s_tc)) return;  // uniform over the workgroup
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   __syncthreads();
   LSTAMP(0)
@@ -419,13 +423,6 @@ __global__ __launch_bounds__(256, 3) void lstm_layer_split_kernel(LstmArgs a) {
   const int gcol = coltile * BN + (lane & 31);
   const int lr = lane & 31, lh = lane >> 5;
   tsg_f32x16 acc[4];
-  float cprev[16];
-#pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const int r = wave * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
-    const long long pv = s_prev[r];
-    cprev[i] = a.c[(size_t)(pv >= 0 ? pv : 0) * hp + u];
-  }
   if (LAYER0) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
@@ -442,91 +439,127 @@ __global__ __launch_bounds__(256, 3) void lstm_layer_split_kernel(LstmArgs a) {
       for (int i = 0; i < 16; ++i) acc[g][i] = bv;
     }
   }
-  // this lane's A row: the state row of (wave's row lr) in the lower layer's output (k < hp) or in its own
-  // previous state (k >= hp for layers above 0, all k for layer 0)
-  const long long my_prev = s_prev[wave * 32 + lr], my_out = s_out[wave * 32 + lr];
+  // The A operand: row r of the wave's 32 rows is the state row of that work item in the lower layer's output
+  // (k < hp) or in its own previous state (k >= hp for layers above 0, all k for layer 0); a k-tile is 128
+  // bytes of it.  Lane (lr, lh) of the matrix-core fragment needs 64 bytes of ROW lr, but a load in which every
+  // lane reads its own row makes the four lanes of a quad touch four cache lines per instruction, and the
+  // address path then takes twice as long as the matrix cores.  So the tile is fetched with eight lanes per
+  // row (instruction j: rows (lane >> 3) + 8 j, 16-byte piece lane & 7: whole lines), written to the wave's own
+  // LDS stretch, and read back in fragment order.
   const unsigned* hs_own = reinterpret_cast<const unsigned*>(a.h);
   const unsigned* hs_below = reinterpret_cast<const unsigned*>(a.h_below);
-  long long ab_prev[4] = {0, 0, 0, 0}, ab_out[4] = {0, 0, 0, 0};  // TSG_ABLATE 37 only
-  if (TSG_ABLATE == 37) {
-    for (int j_ = 0; j_ < 4; ++j_) {
-      ab_prev[j_] = s_prev[wave * 32 + (lane >> 3) + 8 * j_];
-      ab_out[j_] = s_out[wave * 32 + (lane >> 3) + 8 * j_];
-    }
+  int rprev[4], rout[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    rprev[j] = s_prev[wave * 32 + (lane >> 3) + 8 * j];
+    rout[j] = s_out[wave * 32 + (lane >> 3) + 8 * j];
   }
   const _Float16* wimg = reinterpret_cast<const _Float16*>(a.wt) + (size_t)coltile * nkt * (2 * BN * BK);
-  // prefetch registers: the gathered state rows (HBM latency) run two k-tiles ahead, the weights (L2) one
-  tsg_u4 na0, na1, na2, na3, ma0, ma1, ma2, ma3, nb0, nb1, nb2, nb3;
-  unsigned amask_n = 0, amask_m = 0;
-#define TSG_GLOAD_ROWS(KT, R0, R1, R2, R3, MASK)                                                              \
-  {                                                                                                          \
-    const int k0_ = (KT) * BK;                                                                               \
-    const bool below_ = !LAYER0 && (k0_ < hp);                                                               \
-    const long long ridx_ = below_ ? my_out : my_prev;                                                       \
-    const unsigned* src_ = (below_ ? hs_below : hs_own) + (size_t)(ridx_ >= 0 ? ridx_ : 0) * hp +            \
-                           ((below_ || LAYER0) ? k0_ : k0_ - hp) + 16 * lh;                                  \
-    MASK = ridx_ >= 0 ? 0xffffffffu : 0u;                                                                    \
-    const tsg_u4* s4_ = reinterpret_cast<const tsg_u4*>(src_);                                               \
-    R0 = s4_[0]; R1 = s4_[1]; R2 = s4_[2]; R3 = s4_[3];                                                      \
-    if (TSG_ABLATE == 37) { /* timing only (wrong operands): the same bytes with four lanes per 64-byte run */ \
-      const unsigned* b_ = (below_ ? hs_below : hs_own) + ((below_ || LAYER0) ? k0_ : k0_ - hp) + 4 * (lane & 7); \
-      const long long* rr_ = below_ ? ab_out : ab_prev;                                                      \
-      R0 = *reinterpret_cast<const tsg_u4*>(b_ + (size_t)(rr_[0] >= 0 ? rr_[0] : 0) * hp);                   \
-      R1 = *reinterpret_cast<const tsg_u4*>(b_ + (size_t)(rr_[1] >= 0 ? rr_[1] : 0) * hp);                   \
-      R2 = *reinterpret_cast<const tsg_u4*>(b_ + (size_t)(rr_[2] >= 0 ? rr_[2] : 0) * hp);                   \
-      R3 = *reinterpret_cast<const tsg_u4*>(b_ + (size_t)(rr_[3] >= 0 ? rr_[3] : 0) * hp);                   \
-    }                                                                                                        \
+  unsigned* a_st = s_a[wave] + (lane >> 3) * 32 + (((lane & 7) ^ ((lane >> 3) & 7)) << 2);  // + j * 256 words
+  const unsigned* a_ld = s_a[wave] + lr * 32;
+  tsg_u4 ma0, ma1, ma2, ma3, nb0, nb1, nb2, nb3;  // in flight: rows of the next tile but one... see the loop
+#define TSG_GLOAD_ROWS(KT)                                                                                  \
+  {                                                                                                         \
+    const int k0_ = (KT) * BK;                                                                              \
+    const bool below_ = !LAYER0 && (k0_ < hp);                                                              \
+    const unsigned* b_ = (below_ ? hs_below : hs_own) + ((below_ || LAYER0) ? k0_ : k0_ - hp) + 4 * (lane & 7); \
+    const int r0_ = below_ ? rout[0] : rprev[0], r1_ = below_ ? rout[1] : rprev[1];                         \
+    const int r2_ = below_ ? rout[2] : rprev[2], r3_ = below_ ? rout[3] : rprev[3];                         \
+    ma0 = *reinterpret_cast<const tsg_u4*>(b_ + (size_t)(r0_ >= 0 ? r0_ : 0) * hp);                         \
+    ma1 = *reinterpret_cast<const tsg_u4*>(b_ + (size_t)(r1_ >= 0 ? r1_ : 0) * hp);                         \
+    ma2 = *reinterpret_cast<const tsg_u4*>(b_ + (size_t)(r2_ >= 0 ? r2_ : 0) * hp);                         \
+    ma3 = *reinterpret_cast<const tsg_u4*>(b_ + (size_t)(r3_ >= 0 ? r3_ : 0) * hp);                         \
+  }
+  // rows without a parent state (row index -1) contribute zeros: masked here, when the data is first touched
+#define TSG_ASTORE(KT)                                                                                      \
+  {                                                                                                         \
+    const bool below_ = !LAYER0 && ((KT) * BK < hp);                                                        \
+    const unsigned m0_ = ~(unsigned)((below_ ? rout[0] : rprev[0]) >> 31);                                  \
+    const unsigned m1_ = ~(unsigned)((below_ ? rout[1] : rprev[1]) >> 31);                                  \
+    const unsigned m2_ = ~(unsigned)((below_ ? rout[2] : rprev[2]) >> 31);                                  \
+    const unsigned m3_ = ~(unsigned)((below_ ? rout[3] : rprev[3]) >> 31);                                  \
+    *reinterpret_cast<tsg_u4*>(a_st) = ma0 & m0_;                                                           \
+    *reinterpret_cast<tsg_u4*>(a_st + 256) = ma1 & m1_;                                                     \
+    *reinterpret_cast<tsg_u4*>(a_st + 512) = ma2 & m2_;                                                     \
+    *reinterpret_cast<tsg_u4*>(a_st + 768) = ma3 & m3_;                                                     \
+  }
+#define TSG_ALOAD(C0, C1, C2, C3)                                                                           \
+  {                                                                                                         \
+    C0 = *reinterpret_cast<const tsg_u4*>(a_ld + (((4 * lh + 0) ^ (lr & 7)) << 2));                         \
+    C1 = *reinterpret_cast<const tsg_u4*>(a_ld + (((4 * lh + 1) ^ (lr & 7)) << 2));                         \
+    C2 = *reinterpret_cast<const tsg_u4*>(a_ld + (((4 * lh + 2) ^ (lr & 7)) << 2));                         \
+    C3 = *reinterpret_cast<const tsg_u4*>(a_ld + (((4 * lh + 3) ^ (lr & 7)) << 2));                         \
   }
   auto gload_w = [&](int kt) {
     const tsg_u4* w4 = reinterpret_cast<const tsg_u4*>(wimg + (size_t)kt * (2 * BN * BK) + (size_t)tid * 32);
     nb0 = w4[0]; nb1 = w4[1]; nb2 = w4[2]; nb3 = w4[3];
   };
+  const int w_sw = ((tid & 127) >> 2) & 3;  // chunk swizzle of this thread's column
   auto lstore = [&](int buf) {
     _Float16* dst = (tid < BN) ? &tb[buf].major[tid][0] : &tb[buf].minor[tid - BN][0];
-    tsg_u4* d4 = reinterpret_cast<tsg_u4*>(dst);
-    d4[0] = nb0; d4[1] = nb1; d4[2] = nb2; d4[3] = nb3;
+    *reinterpret_cast<tsg_u4*>(dst + 8 * (0 ^ w_sw)) = nb0;
+    *reinterpret_cast<tsg_u4*>(dst + 8 * (1 ^ w_sw)) = nb1;
+    *reinterpret_cast<tsg_u4*>(dst + 8 * (2 ^ w_sw)) = nb2;
+    *reinterpret_cast<tsg_u4*>(dst + 8 * (3 ^ w_sw)) = nb3;
   };
-  TSG_GLOAD_ROWS(0, na0, na1, na2, na3, amask_n)
+  const int b_sw = (lr >> 2) & 3;  // the same swizzle on the read side: column g * 32 + lr
+  tsg_u4 ca0, ca1, ca2, ca3;
+  TSG_GLOAD_ROWS(0)
   gload_w(0);
-  if (nkt > 1) TSG_GLOAD_ROWS(1, ma0, ma1, ma2, ma3, amask_m)
+  TSG_ASTORE(0)
+  if (nkt > 1) TSG_GLOAD_ROWS(1)
   lstore(0);
-  tsg_u4 ca0 = na0 & amask_n, ca1 = na1 & amask_n, ca2 = na2 & amask_n, ca3 = na3 & amask_n;
+  TSG_ALOAD(ca0, ca1, ca2, ca3)
   __syncthreads();
   LSTAMP(1)
   const tsg_h8 scale = {(_Float16)2048.0f, (_Float16)2048.0f, (_Float16)2048.0f, (_Float16)2048.0f,
                         (_Float16)2048.0f, (_Float16)2048.0f, (_Float16)2048.0f, (_Float16)2048.0f};
-  for (int kt = 0, cur = 0; kt < nkt; ++kt, cur ^= 1) {
-    const bool more = kt + 1 < nkt;
-    // rows of tile kt+1 are in flight in m*; move them to n* and start tile kt+2
-    if (more) {
-      na0 = ma0; na1 = ma1; na2 = ma2; na3 = ma3;
-      amask_n = amask_m;
-      gload_w(kt + 1);
-    }
-    if (kt + 2 < nkt) TSG_GLOAD_ROWS(kt + 2, ma0, ma1, ma2, ma3, amask_m)
-    const TileB16& t = tb[cur];
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const tsg_u4 w0 = s == 0 ? ca0 : ca2, w1 = s == 0 ? ca1 : ca3;
-      const tsg_h8 amaj = tsg_pack_halves(w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, 0x05040100u);
-      const tsg_h8 amin = tsg_pack_halves(w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, 0x07060302u);
-      const tsg_h8 amaj_s = amaj * scale;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int col = g * 32 + lr;
-        const tsg_h8 bmaj = *reinterpret_cast<const tsg_h8*>(&t.major[col][16 * lh + 8 * s]);
-        const tsg_h8 bmin = *reinterpret_cast<const tsg_h8*>(&t.minor[col][16 * lh + 8 * s]);
-        acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(amaj_s, bmaj, acc[g], 0, 0, 0);
-        acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(amaj, bmin, acc[g], 0, 0, 0);
-        acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(amin, bmaj, acc[g], 0, 0, 0);
-      }
-    }
-    if (more) {
-      lstore(cur ^ 1);
-      ca0 = na0 & amask_n; ca1 = na1 & amask_n; ca2 = na2 & amask_n; ca3 = na3 & amask_n;
-    }
-    __syncthreads();
+  // one k-tile: the rows of tile KT+1 (requested one step ago) go to the wave's LDS stretch, whose previous
+  // content (tile KT) is already in ca*; then the rows of tile KT+2 and the weights of tile KT+1 are requested
+#define TSG_KSTEP(KT, CUR, MORE)                                                                            \
+  {                                                                                                         \
+    if (MORE) {                                                                                             \
+      gload_w((KT) + 1);                                                                                    \
+      TSG_ASTORE((KT) + 1)                                                                                  \
+      if ((KT) + 2 < nkt) TSG_GLOAD_ROWS((KT) + 2)                                                          \
+    }                                                                                                       \
+    const TileB16& t_ = tb[CUR];                                                                            \
+    _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                         \
+      const tsg_u4 w0 = s == 0 ? ca0 : ca2, w1 = s == 0 ? ca1 : ca3;                                        \
+      const tsg_h8 amaj = tsg_pack_halves(w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, 0x05040100u);     \
+      const tsg_h8 amin = tsg_pack_halves(w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, 0x07060302u);     \
+      const tsg_h8 amaj_s = amaj * scale;                                                                   \
+      _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                       \
+        const int col = g * 32 + lr;                                                                        \
+        const tsg_h8 bmaj = *reinterpret_cast<const tsg_h8*>(&t_.major[col][8 * ((2 * lh + s) ^ b_sw)]);    \
+        const tsg_h8 bmin = *reinterpret_cast<const tsg_h8*>(&t_.minor[col][8 * ((2 * lh + s) ^ b_sw)]);    \
+        acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(amaj_s, bmaj, acc[g], 0, 0, 0);                     \
+        acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(amaj, bmin, acc[g], 0, 0, 0);                       \
+        acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(amin, bmaj, acc[g], 0, 0, 0);                       \
+      }                                                                                                     \
+    }                                                                                                       \
+    if (MORE) {                                                                                             \
+      lstore((CUR) ^ 1);                                                                                    \
+      TSG_ALOAD(ca0, ca1, ca2, ca3)                                                                         \
+      __syncthreads();                                                                                      \
+    }                                                                                                       \
   }
+  int kt = 0, cur = 0;
+  for (; kt + 1 < nkt; ++kt, cur ^= 1) TSG_KSTEP(kt, cur, true)
+  // previous cell states, for the epilogue: requested before the last k-tile, where the prefetch registers of
+  // the loop are free (held across the whole loop they are sixteen registers too many)
+  float cprev[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int r = wave * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+    const int pv = s_prev[r];
+    cprev[i] = a.c[(size_t)(pv >= 0 ? pv : 0) * hp + u];
+  }
+  TSG_KSTEP(kt, cur, false)
+#undef TSG_KSTEP
+#undef TSG_GLOAD_ROWS
+#undef TSG_ASTORE
+#undef TSG_ALOAD
   LSTAMP(2)
   float4 tq[4];
   auto tload = [&](int i) {
