@@ -490,17 +490,18 @@ __global__ __launch_bounds__(256, 3) void lstm_layer_split_kernel(LstmArgs a) {
     C2 = *reinterpret_cast<const tsg_u4*>(a_ld + (((4 * lh + 2) ^ (lr & 7)) << 2));                         \
     C3 = *reinterpret_cast<const tsg_u4*>(a_ld + (((4 * lh + 3) ^ (lr & 7)) << 2));                         \
   }
+  // the 16 KB weight tile is 1 024 pieces of 16 bytes; thread tid takes pieces tid, tid + 256, ...: every load
+  // of a wave reads 1 KB of consecutive bytes.  Piece p: plane p / 512, column (p % 512) / 4, chunk p % 4.
   auto gload_w = [&](int kt) {
-    const tsg_u4* w4 = reinterpret_cast<const tsg_u4*>(wimg + (size_t)kt * (2 * BN * BK) + (size_t)tid * 32);
-    nb0 = w4[0]; nb1 = w4[1]; nb2 = w4[2]; nb3 = w4[3];
+    const tsg_u4* w4 = reinterpret_cast<const tsg_u4*>(wimg + (size_t)kt * (2 * BN * BK)) + tid;
+    nb0 = w4[0]; nb1 = w4[256]; nb2 = w4[512]; nb3 = w4[768];
   };
-  const int w_sw = ((tid & 127) >> 2) & 3;  // chunk swizzle of this thread's column
+  const int w_off = (tid >> 2) * 32 + 8 * ((tid & 3) ^ ((tid >> 4) & 3));  // column tid / 4 (+ 64), swizzled chunk
   auto lstore = [&](int buf) {
-    _Float16* dst = (tid < BN) ? &tb[buf].major[tid][0] : &tb[buf].minor[tid - BN][0];
-    *reinterpret_cast<tsg_u4*>(dst + 8 * (0 ^ w_sw)) = nb0;
-    *reinterpret_cast<tsg_u4*>(dst + 8 * (1 ^ w_sw)) = nb1;
-    *reinterpret_cast<tsg_u4*>(dst + 8 * (2 ^ w_sw)) = nb2;
-    *reinterpret_cast<tsg_u4*>(dst + 8 * (3 ^ w_sw)) = nb3;
+    *reinterpret_cast<tsg_u4*>(&tb[buf].major[0][0] + w_off) = nb0;
+    *reinterpret_cast<tsg_u4*>(&tb[buf].major[64][0] + w_off) = nb1;
+    *reinterpret_cast<tsg_u4*>(&tb[buf].minor[0][0] + w_off) = nb2;
+    *reinterpret_cast<tsg_u4*>(&tb[buf].minor[64][0] + w_off) = nb3;
   };
   const int b_sw = (lr >> 2) & 3;  // the same swizzle on the read side: column g * 32 + lr
   tsg_u4 ca0, ca1, ca2, ca3;
