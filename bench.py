@@ -139,6 +139,39 @@ def gat_encoder_timing(model, net, cfg, reps=5):
             'frac': byts / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS}
 
 
+def measured_peaks(device):
+    """what this very box reaches on a plain copy and on a dense f16 matrix product (torch kernels:
+    a device-to-device copy of 1 GiB, an 8192^3 f16 matmul through hipBLASLt), next to the vendor peaks."""
+    import torch
+    out = {}
+    try:
+        n = 1 << 28
+        src = torch.empty(n, dtype=torch.float32, device=device).fill_(1.0)
+        dst = torch.empty_like(src)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        dst.copy_(src)
+        ev[0].record()
+        for _ in range(10):
+            dst.copy_(src)
+        ev[1].record()
+        torch.cuda.synchronize()
+        out['hbm_copy_GBs'] = 10 * 2.0 * n * 4 / (ev[0].elapsed_time(ev[1]) * 1e-3) / 1e9
+        del src, dst
+        a = torch.randn((8192, 8192), dtype=torch.float16, device=device)
+        b = torch.randn((8192, 8192), dtype=torch.float16, device=device)
+        c = a @ b
+        ev[0].record()
+        for _ in range(10):
+            c = a @ b
+        ev[1].record()
+        torch.cuda.synchronize()
+        out['f16_gemm_TFLOPs'] = 10 * 2.0 * 8192 ** 3 / (ev[0].elapsed_time(ev[1]) * 1e-3) / 1e12
+        del a, b, c
+    except RuntimeError as e:      # e.g. no room left beside the page pool: the vendor peaks stand alone
+        out['error'] = str(e)[:120]
+    return out
+
+
 def cpu_baseline(net, model, cfg, od, budget_s, max_step):
     """The CPU oracle (port of search.py:240-424 + generator_v4.py:56-72) on the first ODs of the workload."""
     import torch
@@ -303,6 +336,12 @@ def main():
                         'unit': d['unit'], 'frac': d['frac'], 'traffic': traffic, 'traffic_source': traffic_src,
                         'avg_launch_ms': d['avg_ms'], 'rows_per_launch': rows_per_launch}
         gat = gat_encoder_timing(model, net, cfg)
+        peaks = measured_peaks(device)
+        for k in list(kern.values()) + ([roofline] if roofline else []):
+            ref = peaks.get('hbm_copy_GBs') if k['bound'] == 'hbm' else (
+                peaks['f16_gemm_TFLOPs'] / 3.0 if args.lstm == 'split' and 'f16_gemm_TFLOPs' in peaks else None)
+            k['measured_peak'] = ref      # this box: device-to-device copy / a third of an 8192^3 f16 matmul
+            k['frac_of_measured'] = k['achieved'] / ref if ref else None
         cpu = None
         if world == 1 and args.cpu_seconds > 0:
             cpu = cpu_baseline(net, model, cfg, od, args.cpu_seconds, args.max_step)
@@ -320,7 +359,7 @@ def main():
             'supersteps': int(sum(s['supersteps'] for s in stats)), 'work_items': int(items),
             'page_waits': int(sum(s['page_waits'] for s in stats)), 'restarts': int(sum(s['restarts'] for s in stats)),
             'min_free_pages': int(min(s['min_free_pages'] for s in stats)),
-            'roofline': roofline, 'kernels': kern, 'gat_encoder': gat, 'cpu_baseline': cpu,
+            'roofline': roofline, 'kernels': kern, 'measured_peaks': peaks, 'gat_encoder': gat, 'cpu_baseline': cpu,
         }
         print(json.dumps(out))
     if world > 1:

@@ -292,6 +292,17 @@ typedef struct tsg_engine {
  * small kernel).  The caller zeroes `shared_counters` itself when it is a separate array. */
 int tsg_engine_reset(const tsg_engine* e, const tsg_graph* g, void* stream);
 
+/* Trajectories out of the expansion records of the searches (the path the reference carries in every SearchNode,
+ * search.py:14-52: trace_loc / trace_tim, and returns at :291-296 / :421-424).  Request i names a search slot and
+ * one of its expanded nodes (index into the slot's exp_meta); with last_rid[i] >= 0 one more point (last_rid[i],
+ * last_tcode[i]) is appended behind it (a successor that was not expanded, e.g. the destination).  Writes
+ * out_rid / out_time [n][lmax] (positions >= lmax are dropped) and out_len[n] (0 for a request out of range).
+ * tsg_engine_run does the same for every search that ends; this entry point serves searches still in flight and
+ * finished slots whose records have not been reused.  last_rid / last_tcode may be NULL. */
+int tsg_reconstruct_paths(const tsg_engine* e, int32_t n, const int32_t* slot, const int32_t* node,
+                          const int32_t* last_rid, const int32_t* last_tcode, int32_t lmax, int32_t* out_rid,
+                          int32_t* out_time, int32_t* out_len, void* stream);
+
 /* Enqueue `n_supersteps` supersteps.  `first_superstep` is the index of the first one (parity
  * selects the ping-pong item counter).  Poll counters[3] == n_od for completion. */
 int tsg_engine_run(const tsg_model* m, const tsg_graph* g, const tsg_od_batch* od, const tsg_engine* e,

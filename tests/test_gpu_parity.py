@@ -142,6 +142,47 @@ def test_g5_astar(road, road_model):
     assert {0, 1, 2} <= set(st)
 
 
+def test_reconstruct_paths(road, road_model):
+    """tsg_reconstruct_paths against a host walk of the same expansion records: one search per slot (slots >= OD
+    pairs, so no slot is refilled), the path of each search's LAST expanded node, with and without one more
+    point appended, and a request out of range."""
+    from ts_trajgen_amd.search import Searcher
+    cases = load_json('g5_astar.json')['cases'][:24]
+    s = Searcher(DEV, road.adjacent_list, road.rid_gps, road.road_length, road.rtd)
+    res = s.generate(road_model, [c['start'] for c in cases], [c['start_time'] for c in cases],
+                     [c['des'] for c in cases], [c['default_len'] for c in cases],
+                     max_step=[c['max_step'] for c in cases], slots=32)
+    eng = list(s._engines.values())[0]
+    ss = eng.slot_state.cpu().numpy()
+    em = eng.exp_meta.cpu().numpy()                      # [slots][exp_cap][parent, rid, tcode, depth]
+    used = [b for b in range(eng.slots) if ss[b, 6] == 1 and ss[b, 5] > 0]      # SS_GEN == 1, SS_EXP_N > 0
+    assert len(used) >= len(cases) - 4
+    node = [int(ss[b, 5]) - 1 for b in used]
+    lmax = 64
+    rid, tim, ln = eng.reconstruct_paths(used, node, lmax=lmax)
+    rid2, tim2, ln2 = eng.reconstruct_paths(used + [10 ** 6], node + [0], last_rid=[7] * len(used) + [7],
+                                            last_tcode=[11] * len(used) + [11], lmax=lmax)
+    rid, tim, ln, rid2, tim2, ln2 = [t.cpu().numpy() for t in (rid, tim, ln, rid2, tim2, ln2)]
+    assert ln2[-1] == 0
+    for k, (b, nd) in enumerate(zip(used, node)):
+        want_r, want_t, cur = [], [], nd
+        while cur >= 0:
+            want_r.append(int(em[b, cur, 1]))
+            want_t.append(int(em[b, cur, 2]))
+            cur = int(em[b, cur, 0])
+        want_r, want_t = want_r[::-1], want_t[::-1]
+        assert len(want_r) == int(em[b, nd, 3]) == ln[k]
+        od = int(ss[b, 1])                                  # SS_OD: the OD pair this slot ran
+        assert want_r[0] == cases[od]['start']
+        n = min(len(want_r), lmax)
+        assert rid[k, :n].tolist() == want_r[:n] and tim[k, :n].tolist() == want_t[:n]
+        assert ln2[k] == ln[k] + 1
+        n2 = min(len(want_r) + 1, lmax)
+        assert rid2[k, :n2].tolist() == (want_r + [7])[:n2] and tim2[k, :n2].tolist() == (want_t + [11])[:n2]
+        for a, c in zip(want_r, want_r[1:]):
+            assert c in road.adjacent_list[str(a)]
+
+
 def test_g5_single_od_api(road, road_model):
     """Reference call signature, one OD per call (search.py:240)."""
     from ts_trajgen_amd.search import Searcher

@@ -466,6 +466,51 @@ __device__ __forceinline__ HeapEnt heap_pop(uint64_t* h, int& n, const int32_t* 
   return ret;
 }
 
+// A trajectory out of the expansion records of one search: (rid, tcode) is its last point (depth = its length),
+// `parent` the expanded node before it; the chain of parents fills the positions in front (search.py:291-296:
+// the popped node's trace; :421-424: the fallback trace).  Positions >= lmax are dropped.
+__device__ __forceinline__ void write_path(const int32_t* em, int parent, int rid, int tcode, int depth, int32_t* orid,
+                                           int32_t* otim, int lmax) {
+  int i = depth - 1;
+  if (i < lmax) {
+    orid[i] = rid;
+    otim[i] = tcode;
+  }
+  int cur = parent;
+  --i;
+  while (cur >= 0 && i >= 0) {
+    if (i < lmax) {
+      orid[i] = em[(size_t)cur * EM_WORDS + EM_RID];
+      otim[i] = em[(size_t)cur * EM_WORDS + EM_TCODE];
+    }
+    cur = em[(size_t)cur * EM_WORDS + EM_PARENT];
+    --i;
+  }
+}
+
+__global__ void reconstruct_paths_kernel(tsg_engine e, int n, const int32_t* slot, const int32_t* node,
+                                         const int32_t* last_rid, const int32_t* last_tcode, int lmax,
+                                         int32_t* out_rid, int32_t* out_time, int32_t* out_len) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int b = slot[i], nd = node[i];
+  if (b < 0 || b >= e.slots || nd < 0 || nd >= e.exp_cap) {
+    out_len[i] = 0;
+    return;
+  }
+  const int32_t* em = e.exp_meta + (size_t)b * e.exp_cap * EM_WORDS;
+  const int32_t* r = em + (size_t)nd * EM_WORDS;
+  int parent = r[EM_PARENT], rid = r[EM_RID], tcode = r[EM_TCODE], depth = r[EM_DEPTH];
+  if (last_rid && last_rid[i] >= 0) {  // one more point behind the expanded node (a successor that was not expanded)
+    parent = nd;
+    rid = last_rid[i];
+    tcode = last_tcode ? last_tcode[i] : 0;
+    depth += 1;
+  }
+  write_path(em, parent, rid, tcode, depth, out_rid + (size_t)i * lmax, out_time + (size_t)i * lmax, lmax);
+  out_len[i] = depth;
+}
+
 // TSG_SPW searches per wave (one lane each, the other lanes idle): the work is a chain of dependent small
 // accesses, so what matters is how many chains are in flight and how long a search waits for the slowest
 // search of its wave (every divergent loop runs to the longest trip count in the wave), not lane use.
@@ -910,23 +955,8 @@ __global__ __launch_bounds__(256) void frontier_kernel(EngineDev D, int superste
     {
       const int lmax = od.lmax;
       if (fin_depth > lmax) fin_status |= TSG_STATUS_OVERFLOW;
-      int32_t* orid = od.out_rid + (size_t)odi * lmax;
-      int32_t* otim = od.out_time + (size_t)odi * lmax;
-      int i = fin_depth - 1;
-      if (i < lmax) {
-        orid[i] = fin_rid;
-        otim[i] = fin_tcode;
-      }
-      int cur = fin_parent;
-      --i;
-      while (cur >= 0 && i >= 0) {
-        if (i < lmax) {
-          orid[i] = em[(size_t)cur * EM_WORDS + EM_RID];
-          otim[i] = em[(size_t)cur * EM_WORDS + EM_TCODE];
-        }
-        cur = em[(size_t)cur * EM_WORDS + EM_PARENT];
-        --i;
-      }
+      write_path(em, fin_parent, fin_rid, fin_tcode, fin_depth, od.out_rid + (size_t)odi * lmax,
+                 od.out_time + (size_t)odi * lmax, lmax);
       od.out_len[odi] = fin_depth;
       od.out_status[odi] = fin_status;
       od.out_steps[odi] = step;
@@ -1085,6 +1115,19 @@ extern "C" int tsg_engine_reset(const tsg_engine* e, const tsg_graph* g, void* s
   TSG_HIP_TRY(hipMemsetAsync(e->items, 0, tsg_item_positions(e->slots) * IT_WORDS * 4, s));
   TSG_HIP_TRY(hipMemsetAsync(e->item_counts, 0, tsg_item_count_words(e->slots) * 4, s));
   hipLaunchKernelGGL(engine_init_pages_kernel, dim3(tsg_cdiv(e->n_pages, 256)), dim3(256), 0, s, *e);
+  TSG_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int tsg_reconstruct_paths(const tsg_engine* e, int32_t n, const int32_t* slot, const int32_t* node,
+                                     const int32_t* last_rid, const int32_t* last_tcode, int32_t lmax,
+                                     int32_t* out_rid, int32_t* out_time, int32_t* out_len, void* stream) {
+  if (!e || e->slots <= 0 || e->exp_cap <= 0 || !e->exp_meta) return TSG_E_INVALID;
+  if (e->exp_meta_bytes < (size_t)e->slots * e->exp_cap * EM_WORDS * 4) return TSG_E_TOO_SMALL;
+  if (n < 0 || lmax <= 0 || !slot || !node || !out_rid || !out_time || !out_len) return TSG_E_INVALID;
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(reconstruct_paths_kernel, dim3(tsg_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, *e, n, slot,
+                     node, last_rid, last_tcode, lmax, out_rid, out_time, out_len);
   TSG_LAUNCH_CHECK();
   return 0;
 }

@@ -425,6 +425,31 @@ class AStarEngine(object):
         return AStarEngine.fixed_bytes_per_slot(graph, max_step, max_prefix) + pps * AStarEngine.bytes_per_page(tables)
 
     @torch.no_grad()
+    def reconstruct_paths(self, slot, node, last_rid=None, last_tcode=None, lmax=None):
+        """Trajectories out of the expansion records (tsg_reconstruct_paths): request i = (search slot, index of
+        one of its expanded nodes) [+ one more point (last_rid[i], last_tcode[i]) behind it].  Returns device
+        tensors (rid [n, lmax], time [n, lmax], len [n]).  Valid for searches in flight and for finished slots
+        whose records have not been reused by a later OD pair."""
+        L = _lib.lib()
+        dev = self.device
+        lmax = int(lmax or self.lmax)
+
+        def dv(a):
+            return None if a is None else torch.as_tensor(np.asarray(a, dtype=np.int32)).to(dev)
+        slot_t, node_t, lr_t, lt_t = dv(slot), dv(node), dv(last_rid), dv(last_tcode)
+        n = int(slot_t.numel())
+        if int(node_t.numel()) != n or (lr_t is not None and int(lr_t.numel()) != n) or (
+                lt_t is not None and int(lt_t.numel()) != n):
+            raise ValueError('slot / node / last_rid / last_tcode must have one entry per request')
+        rid = torch.zeros((n, lmax), dtype=torch.int32, device=dev)
+        tim = torch.zeros((n, lmax), dtype=torch.int32, device=dev)
+        ln = torch.zeros(n, dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(L.tsg_reconstruct_paths(C.byref(self.c_engines[0]), n, _lib.ptr(slot_t), _lib.ptr(node_t),
+                                               _lib.ptr(lr_t), _lib.ptr(lt_t), lmax, _lib.ptr(rid), _lib.ptr(tim),
+                                               _lib.ptr(ln), _lib.current_stream()), 'tsg_reconstruct_paths')
+        return rid, tim, ln
+
     def run(self, prefix_ptr, prefix_rid, prefix_time, des, default_len, max_step, allow_label=None,
             poplog_cap=0, chunk=32, return_device=False, profile_every=0):
         """Run all OD pairs; returns dict(rid [n, lmax], time, len, status, steps[, poplog_*])."""
