@@ -224,3 +224,21 @@ def test_config1_state_page_pool_under_pressure(porto):
     for k in ('rid', 'time', 'len', 'status', 'steps'):
         assert torch.equal(ref2[k], got2[k]), k
     assert st2['page_waits'] > 0 and st2['restarts'] > 0, st2
+
+
+def test_config1_work_list_over_several_regions(porto):
+    """The superstep's work list is kept per region of 4 096 slots (include/tsg.h, tsg_engine.items): an engine
+    of one full and one partial region (4 296 slots, a pool well below the worst case) gives the trajectories of
+    a 512-slot engine, bit for bit."""
+    from ts_trajgen_amd.search import Searcher
+    net, model, cfg, od = porto
+    s = Searcher(DEV, net.adjacent_list, net.rid_gps, net.road_length, net.road_time_distribution)
+    two = {k: np.concatenate([v, v]) for k, v in od.items()}
+    args = (model, two['start'], two['start_time'], two['des'], two['default_len'])
+    ref = s.generate(*args, max_step=600, slots=512, lmax=256)
+    pps = (1 + 600 + 63) // 64
+    got = s.generate(*args, max_step=600, slots=4296, lmax=256, pool_pages=4296 * pps // 3, ramp_steps=100)
+    for k in ('rid', 'time', 'len', 'status', 'steps'):
+        assert torch.equal(ref[k], got[k]), k
+    half = len(od['des'])
+    assert torch.equal(got['rid'][:half], got['rid'][half:])       # the same OD pair twice: the same trajectory
