@@ -81,6 +81,11 @@ def test_g234_predict(road_model):
         np.testing.assert_allclose(h.cpu().numpy()[0], c['h'], rtol=RTOL)
         np.testing.assert_allclose(p.cpu().numpy()[0], c['p'], rtol=RTOL)
         np.testing.assert_allclose(torch.log(p).cpu().numpy()[0], c['logp'], rtol=RTOL)
+        # the halves under their reference names (function_g_fc.py:206, distance_gat_fc.py:136)
+        g2 = road_model.function_g.predict_g(tl, tt, dt, cs, cd)
+        h2 = road_model.function_h.predict_next(cs, dt, cd)
+        np.testing.assert_allclose(g2.cpu().numpy()[0], c['g'], rtol=RTOL)
+        np.testing.assert_allclose(h2.cpu().numpy()[0], c['h'], rtol=RTOL)
 
 
 def test_predict_batched_with_mask(road_model):

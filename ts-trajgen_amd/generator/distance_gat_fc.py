@@ -71,5 +71,16 @@ class DistanceGatFC(nn.Module):
         if self.node_emb_feature is None:
             self.update_node_emb()
 
+    def predict_next(self, candidate_set, des, candidate_distance):
+        """softmax over the candidates of function H alone (distance_gat_fc.py:136-157); same arguments."""
+        from .generator_v4 import owner_of
+        owner = owner_of(self, 'function_h')
+        if owner is None:
+            raise RuntimeError('DistanceGatFC.predict_next runs through the device tables of its GeneratorV4: '
+                               'construct the module as GeneratorV4(config, data_feature).function_h')
+        # the scoring kernel evaluates G and H together; G gets a one-point trace (the first candidate, time 0)
+        loc = candidate_set[:, :1]
+        return owner.predict_parts(loc, torch.zeros_like(loc), des, candidate_set, candidate_distance)[2]
+
     def forward(self, *args, **kwargs):
         raise NotImplementedError('training forward of function H is outside the generation path')

@@ -36,6 +36,15 @@ class FunctionGFC(nn.Module):
         self.dropout = nn.Dropout(p=self.dropout_p)
         self.out_fc = nn.Linear(in_features=self.hidden_size, out_features=data_feature['road_num'])
 
+    def predict_g(self, trace_loc, trace_time, des, candidate_set, candidate_dis, trace_mask=None):
+        """softmax over the candidates of function G alone (function_g_fc.py:206-221); same arguments."""
+        from .generator_v4 import owner_of
+        owner = owner_of(self, 'function_g')
+        if owner is None:
+            raise RuntimeError('FunctionGFC.predict_g runs through the device tables of its GeneratorV4: '
+                               'construct the module as GeneratorV4(config, data_feature).function_g')
+        return owner.predict_parts(trace_loc, trace_time, des, candidate_set, candidate_dis, trace_mask)[1]
+
     def forward(self, *args, **kwargs):
         raise NotImplementedError('use GeneratorV4.predict / the batched engine; function G alone has no '
                                   'caller on the generation path')

@@ -4,11 +4,21 @@
 candidates, computed by libtsg.so (incremental LSTM cell on MFMA, attention, gathered out_fc rows,
 factored H).  Device tables are (re)built lazily and invalidated by `load_state_dict` / `.to()`.
 """
+import weakref
+
 import torch
 import torch.nn as nn
 
 from .distance_gat_fc import DistanceGatFC
 from .function_g_fc import FunctionGFC
+
+
+OWNERS = weakref.WeakValueDictionary()
+
+
+def owner_of(half, attr):
+    g = OWNERS.get(id(half))
+    return g if g is not None and getattr(g, attr, None) is half else None
 
 
 class GeneratorV4(nn.Module):
@@ -20,6 +30,13 @@ class GeneratorV4(nn.Module):
         self.function_h = DistanceGatFC(config['function_h'], data_feature)
         self._tables = None
         self._tables_key = None
+        self._adopt()
+
+    def _adopt(self):
+        """predict_g / predict_next of the two halves run through the device tables of the whole model: the halves
+        find it here (weak values, keyed by the half's id: no module cycle, nothing extra to pickle)."""
+        OWNERS[id(self.function_g)] = self
+        OWNERS[id(self.function_h)] = self
 
     # -- device tables ---------------------------------------------------------------------------
     def _key(self):
@@ -31,6 +48,7 @@ class GeneratorV4(nn.Module):
         if self.training:
             raise RuntimeError('generation is inference-only: call .train(False) first '
                                '(our_model_generate.py:399)')
+        self._adopt()
         key = self._key()
         if self._tables is None or self._tables_key != key:
             self.function_h.node_emb_feature = None
