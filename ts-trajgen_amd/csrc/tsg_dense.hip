@@ -12,9 +12,7 @@
 #include "tsg_common.h"
 
 #ifndef TSG_ABLATE
-#ifndef TSG_ABLATE
-#define TSG_ABLATE 0  // timing-only ablation builds; 0 in the shipped library
-#endif
+#define TSG_ABLATE 0  // timing-only ablation builds (tools/build_variant.sh); 0 in the shipped library
 #endif
 
 #define BM 128

@@ -5,7 +5,7 @@
 #include "tsg_device.h"
 
 #ifndef TSG_ABLATE
-#define TSG_ABLATE 0  // timing-only ablation builds (tools/ablate.sh); 0 in the shipped library
+#define TSG_ABLATE 0  // timing-only ablation builds (tools/build_variant.sh); 0 in the shipped library
 #endif
 
 int tsg_launch_lstm_layer(const tsg_model* m, int layer, int max_rows, const int32_t* n_rows_dev, int n_rows_host,
