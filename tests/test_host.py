@@ -94,3 +94,19 @@ def test_host_geodesic_matches_oracle():
     assert geo.candidate_dis((116.3, 39.9), [(116.3, 39.9)])[0] == 0.0
     # known value: one degree of latitude at the equator on WGS-84 is 110574.389 m
     assert abs(geodesic.geodesic_m(0.0, 0.0, 1.0, 0.0) - 110574.389) < 1e-2
+
+
+def test_ordered_draw_equals_randomstate_choice():
+    """The two-stage search's border-road order (search.py:900-902) is drawn without RandomState.choice's per-call
+    overhead: same uniforms from the same generator, same result, same generator state afterwards."""
+    from ts_trajgen_amd.search import ordered_draw
+    rs = np.random.RandomState(0)
+    for t in range(400):
+        n = int(rs.randint(1, 40))
+        a = rs.randint(0, 10000, size=n)
+        f = np.ones(n) if t % 3 == 0 else rs.randint(1, 50, size=n).astype(float)
+        p = f / np.sum(f)
+        r1, r2 = np.random.RandomState(t), np.random.RandomState(t)
+        for _ in range(2):
+            assert np.array_equal(r1.choice(a, n, p=p, replace=False), ordered_draw(r2, a, p))
+        assert r1.randint(1 << 30) == r2.randint(1 << 30)

@@ -82,6 +82,11 @@ class Searcher(object):
             prefix_rid = np.asarray(start_rids, dtype=np.int32)
             prefix_time = np.asarray(start_times, dtype=np.int32)
             max_prefix = 1
+        elif isinstance(prefixes, tuple) and len(prefixes) == 3 and isinstance(prefixes[0], np.ndarray):
+            prefix_ptr = prefixes[0].astype(np.int32)           # CSR form: (ptr [n+1], rid, time)
+            prefix_rid = prefixes[1].astype(np.int32)
+            prefix_time = prefixes[2].astype(np.int32)
+            max_prefix = (int(np.diff(prefix_ptr).max()) + 63) // 64 * 64
         else:
             lens = np.array([len(p[0]) for p in prefixes], dtype=np.int32)
             prefix_ptr = np.zeros(n_od + 1, dtype=np.int32)
@@ -180,6 +185,30 @@ class Searcher(object):
         if err[0]:
             raise IndexError('list index out of range')
         return locs[0], tims[0]
+
+
+def ordered_draw(rng, a, p):
+    """RandomState.choice(a, len(a), p=p, replace=False) (search.py:900-902) without its per-call overhead
+    (argument checks, np.unique): the same uniforms are taken from `rng` in the same order and the result is the
+    same, element for element (tests/test_host.py compares the two).  Falls back to rng.choice for a generator
+    without random_sample."""
+    if not hasattr(rng, 'random_sample'):
+        return rng.choice(a, len(a), p=p, replace=False)
+    size = len(a)
+    p = p.copy()
+    found = []
+    while len(found) < size:
+        x = rng.random_sample(size - len(found))
+        if found:
+            p[found] = 0
+        cdf = np.cumsum(p)
+        cdf /= cdf[-1]
+        seen = set(found)
+        for v in cdf.searchsorted(x, side='right').tolist():      # first occurrences, in the order drawn
+            if v not in seen:
+                seen.add(v)
+                found.append(v)
+    return a[found]
 
 
 class DoubleLayerSearcher(object):
@@ -288,68 +317,105 @@ class DoubleLayerSearcher(object):
         for i in range(n):
             if is_astar[i] != 1:
                 self.region_fail_find_log.add((sreg[i], dreg[i]))
-        loc = [[int(start_rids[i])] for i in range(n)]
-        tim = [[int(start_times[i])] for i in range(n)]
-        leg = [0] * n              # index into the region path
-        order = [None] * n         # border roads of the current region pair, in the drawn order
-        attempt = [0] * n
-        done = [False] * n
+        # per-OD state as arrays; the Python left per OD pair and round is the choice of its next target
+        des_np = np.asarray(des_rids, dtype=np.int32)
+        dl_np = np.asarray(default_lens, dtype=np.int32)
+        cap = 256
+        p_rid = np.zeros((n, cap), dtype=np.int32)      # the trajectory so far (= prefix of the next leg)
+        p_tim = np.zeros((n, cap), dtype=np.int32)
+        p_rid[:, 0] = np.asarray(start_rids, dtype=np.int32)
+        p_tim[:, 0] = np.asarray(start_times, dtype=np.int32)
+        plen = np.ones(n, dtype=np.int64)
+        leg = np.zeros(n, dtype=np.int64)               # index into the region path
+        nleg = np.array([len(rt) - 1 for rt in region_traces], dtype=np.int64)
+        attempt = np.zeros(n, dtype=np.int64)
+        olen = np.zeros(n, dtype=np.int64)
+        order = [None] * n                              # border roads of the current region pair, in the drawn order
+        done = np.zeros(n, dtype=bool)
+        target = np.zeros(n, dtype=np.int32)
+        allow = np.zeros(n, dtype=np.int32)
         rounds = expansions = 0
         lab = self.road_search.graph().label
-        label_np = lab.cpu().numpy() if lab is not None else None      # host copy: one lookup per OD pair and round
-        while True:
-            act = [i for i in range(n) if not done[i]]
-            if not act:
-                break
-            targets, allow = [], []
-            for i in act:
-                rt = region_traces[i]
-                if leg[i] < len(rt) - 1:
-                    if order[i] is None:
-                        b = self.region_transfer_freq[str(rt[leg[i]])][str(rt[leg[i] + 1])]
+        label_np = lab.cpu().numpy() if lab is not None else None
+        pair_cache = {}
+
+        def set_target(i):
+            rt = region_traces[i]
+            k = int(leg[i])
+            if k < nleg[i]:
+                if order[i] is None:
+                    key = (rt[k], rt[k + 1])
+                    ent = pair_cache.get(key)
+                    if ent is None:
+                        b = self.region_transfer_freq[str(rt[k])][str(rt[k + 1])]
                         freq = np.array(b['transfer_freq'])
-                        if rngs[i] is None:
-                            rngs[i] = np.random.RandomState(int(seeds[i]) if seeds is not None else i)
-                        order[i] = rngs[i].choice(b['transfer_rid'], len(b['transfer_rid']),
-                                                  p=freq / np.sum(freq), replace=False)      # search.py:900-902
-                        attempt[i] = 0
-                    targets.append(int(order[i][attempt[i]]))
-                    allow.append(int(rt[leg[i]]))
-                else:
-                    des = int(des_rids[i])
-                    in_last = label_np is not None and int(label_np[des]) == int(rt[-1])
-                    targets.append(des)
-                    allow.append(int(rt[-1]) if in_last else -1)                             # search.py:925-931
-            pref = [(loc[i], tim[i]) for i in act]
-            lmax = max(256, max(len(p[0]) for p in pref) + 64, int(max(default_lens[i] for i in act)) + 1)
+                        ent = pair_cache[key] = (np.asarray(b['transfer_rid']), freq / np.sum(freq))
+                    if rngs[i] is None:
+                        rngs[i] = np.random.RandomState(int(seeds[i]) if seeds is not None else i)
+                    order[i] = ordered_draw(rngs[i], ent[0], ent[1])                      # search.py:900-902
+                    olen[i] = len(order[i])
+                    attempt[i] = 0
+                target[i] = order[i][attempt[i]]
+                allow[i] = rt[k]
+            else:
+                des = int(des_np[i])
+                in_last = label_np is not None and int(label_np[des]) == int(rt[-1])
+                target[i] = des
+                allow[i] = int(rt[-1]) if in_last else -1                                  # search.py:925-931
+
+        for i in range(n):
+            set_target(i)
+        while True:
+            act = np.flatnonzero(~done)
+            m = int(act.size)
+            if m == 0:
+                break
+            ln = plen[act]
+            ptr = np.zeros(m + 1, dtype=np.int32)
+            np.cumsum(ln, out=ptr[1:])
+            keep = np.arange(cap)[None, :] < ln[:, None]
+            lmax = max(256, int(ln.max()) + 64, int(dl_np[act].max()) + 1)
             lmax = (lmax + 255) // 256 * 256
-            res = self.road_search.generate(road_model, None, None, targets, [int(default_lens[i]) for i in act],
-                                            max_step=ms[act], prefixes=pref, allow_label=allow, slots=slots,
-                                            lmax=lmax)
+            tgt = target[act]
+            res = self.road_search.generate(road_model, None, None, tgt, dl_np[act], max_step=ms[act],
+                                            prefixes=(ptr, p_rid[act][keep], p_tim[act][keep]), allow_label=allow[act],
+                                            slots=slots, lmax=lmax)
             expansions += self.road_search.last_stats.get('expansions', 0)
             rounds += 1
-            r_rid, r_time = res['rid'].numpy(), res['time'].numpy()       # per-OD tensor indexing would dominate
-            r_len, r_status = res['len'].numpy(), res['status'].numpy()
-            for j, i in enumerate(act):
-                k = int(r_len[j])
-                if (int(r_status[j]) & _lib.STATUS_OVERFLOW) or k > r_rid.shape[1]:
-                    raise RuntimeError('trajectory longer than the output row')
-                loc[i] = r_rid[j, :k].tolist()
-                tim[i] = r_time[j, :k].tolist()
-                rt = region_traces[i]
-                if leg[i] < len(rt) - 1:
-                    if loc[i][-1] == targets[j]:                         # search.py:912-914
-                        leg[i] += 1
-                        order[i] = None
-                    else:
-                        self.fail_find_log.add((loc[i][-1], targets[j]))  # search.py:917
-                        attempt[i] += 1
-                        if attempt[i] >= len(order[i]):
-                            done[i] = True                                # search.py:918-919
-                else:
-                    if loc[i][-1] != int(des_rids[i]):
-                        self.fail_find_log.add((loc[i][-1], int(des_rids[i])))   # search.py:932-933
-                    done[i] = True
+            r_rid, r_time = res['rid'].numpy(), res['time'].numpy()
+            r_len, r_status = res['len'].numpy().astype(np.int64), res['status'].numpy()
+            if ((r_status & _lib.STATUS_OVERFLOW) != 0).any() or int(r_len.max()) > r_rid.shape[1]:
+                raise RuntimeError('trajectory longer than the output row')
+            if r_rid.shape[1] > cap:
+                grow = r_rid.shape[1] - cap
+                p_rid = np.concatenate([p_rid, np.zeros((n, grow), dtype=np.int32)], axis=1)
+                p_tim = np.concatenate([p_tim, np.zeros((n, grow), dtype=np.int32)], axis=1)
+                cap = r_rid.shape[1]
+            p_rid[act, :r_rid.shape[1]] = r_rid
+            p_tim[act, :r_rid.shape[1]] = r_time
+            plen[act] = r_len
+            last = r_rid[np.arange(m), r_len - 1]
+            in_leg = leg[act] < nleg[act]
+            hit = last == tgt
+            adv = act[in_leg & hit]                                      # search.py:912-914
+            leg[adv] += 1
+            for i in adv.tolist():
+                order[i] = None
+            miss = in_leg & ~hit
+            if miss.any():
+                self.fail_find_log.update(zip(last[miss].tolist(), tgt[miss].tolist()))      # search.py:917
+                mi = act[miss]
+                attempt[mi] += 1
+                done[mi[attempt[mi] >= olen[mi]]] = True                 # search.py:918-919
+            fin = ~in_leg
+            bad = fin & (last != des_np[act])
+            if bad.any():
+                self.fail_find_log.update(zip(last[bad].tolist(), des_np[act][bad].tolist()))   # search.py:932-933
+            done[act[fin]] = True
+            for i in act[~done[act]].tolist():
+                set_target(i)
+        loc = [p_rid[i, :plen[i]].tolist() for i in range(n)]
+        tim = [p_tim[i, :plen[i]].tolist() for i in range(n)]
         self.last_stats = {'rounds': rounds, 'road_expansions': expansions}
         return loc, tim, is_astar
 
