@@ -324,7 +324,11 @@ int tsg_engine_run_profiled(const tsg_model* m, const tsg_graph* g, const tsg_od
                             int32_t first_superstep, int32_t n_supersteps, void* stream, float* ms_sum_host,
                             int32_t* launches_host);
 
-/* The two kernels of one superstep, individually launchable (tests, profiling). */
+/* One superstep in two calls (tests, profiling, callers that interleave work of their own):
+ * tsg_frontier_expand_select = the frontier kernel and the page-pool control step (search.py:279-300 pop loop,
+ * :385-419 relaxation of the previous expansion); tsg_score_frontier = everything that evaluates the model on the
+ * work items it left (candidate distances :352-357, the recurrent cell, GeneratorV4.predict :359-373).  Calling
+ * the pair in a loop is tsg_engine_run. */
 int tsg_frontier_expand_select(const tsg_graph* g, const tsg_od_batch* od, const tsg_engine* e, int32_t superstep,
                                void* stream);
 int tsg_score_frontier(const tsg_model* m, const tsg_graph* g, const tsg_engine* e, int32_t superstep,

@@ -188,6 +188,27 @@ def test_reconstruct_paths(road, road_model):
             assert c in road.adjacent_list[str(a)]
 
 
+def test_superstep_in_two_calls(road, road_model):
+    """tsg_frontier_expand_select + tsg_score_frontier in a loop == tsg_engine_run (and its HIP-graph replay)."""
+    from ts_trajgen_amd.search import Searcher
+    cases = load_json('g5_astar.json')['cases']
+    s = Searcher(DEV, road.adjacent_list, road.rid_gps, road.road_length, road.rtd)
+    args = (road_model, [c['start'] for c in cases], [c['start_time'] for c in cases], [c['des'] for c in cases],
+            [c['default_len'] for c in cases])
+    kw = dict(max_step=[c['max_step'] for c in cases], slots=16)
+    ref = s.generate(*args, **kw)
+    eng = list(s._engines.values())[0]
+    eng.use_graph, eng.split_calls = False, True
+    got = s.generate(*args, **kw)
+    assert list(s._engines.values())[0] is eng
+    for k in ('rid', 'time', 'len', 'status', 'steps'):
+        assert torch.equal(ref[k], got[k]), k
+    eng.split_calls = False
+    plain = s.generate(*args, **kw)                     # tsg_engine_run without the graph
+    for k in ('rid', 'time', 'len', 'status', 'steps'):
+        assert torch.equal(ref[k], plain[k]), k
+
+
 def test_g5_single_od_api(road, road_model):
     """Reference call signature, one OD per call (search.py:240)."""
     from ts_trajgen_amd.search import Searcher

@@ -1158,6 +1158,11 @@ extern "C" int tsg_score_frontier(const tsg_model* m, const tsg_graph* g, const 
   D.od = tsg_od_batch{};
   launch_cand_dis(D, superstep, (hipStream_t)stream);
   TSG_LAUNCH_CHECK();
+  for (int l = 0; l < m->n_layers; ++l) {
+    rc = tsg_launch_lstm_layer(m, l, e->slots, nullptr, e->slots, nullptr, nullptr, nullptr, nullptr, e,
+                               l > 0 ? e->h[l - 1] : nullptr, e->h[l], e->c[l], (hipStream_t)stream, e->state_format);
+    if (rc) return rc;
+  }
   launch_score_frontier(m, D, superstep, (hipStream_t)stream);
   TSG_LAUNCH_CHECK();
   return 0;

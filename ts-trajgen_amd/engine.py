@@ -400,6 +400,7 @@ class AStarEngine(object):
         self.side_streams = [torch.cuda.Stream(device=dev)]
         self.use_graph = bool(use_graph) and os.environ.get('TSG_NO_GRAPH', '') != '1'   # env: diagnostics only
         self.state_format = int(state_format)
+        self.split_calls = False        # tests: drive the supersteps through tsg_frontier_expand_select + tsg_score_frontier
         self._pinned = [torch.zeros((2, 16), dtype=i32).pin_memory() for _ in range(2)]
         self.last_stats = {}
 
@@ -560,6 +561,13 @@ class AStarEngine(object):
                                            'tsg_engine_graph_create')
                                 graph = gx
                             _lib.check(L.tsg_engine_graph_launch(graph, handle), 'tsg_engine_graph_launch')
+                        elif self.split_calls:      # one superstep = the two individually launchable halves
+                            for k in range(chunk):
+                                _lib.check(L.tsg_frontier_expand_select(C.byref(g), C.byref(od), C.byref(eng),
+                                                                        supersteps + k, handle),
+                                           'tsg_frontier_expand_select')
+                                _lib.check(L.tsg_score_frontier(C.byref(m), C.byref(g), C.byref(eng), supersteps + k,
+                                                                handle), 'tsg_score_frontier')
                         else:
                             _lib.check(L.tsg_engine_run(C.byref(m), C.byref(g), C.byref(od), C.byref(eng), supersteps,
                                                         chunk, handle), 'tsg_engine_run')
