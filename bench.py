@@ -211,9 +211,8 @@ def main():
     net, net_name = build_network(args.config)
     # OD pairs for all ranks (seeded), sharded round-robin by index; BFS default_len before the GPU is touched
     n_total = args.ods * world
-    od_all = synth.make_od_pairs(net, n_total, seed=2, workers=min(16, os.cpu_count() or 1),
-                                 default_len='lattice' if args.config == 'stress' else 'hops')
-    od = {k: v[rank::world].copy() for k, v in od_all.items()}
+    od = synth.make_od_pairs(net, n_total, seed=2, workers=max(1, min(16, (os.cpu_count() or 1) // world)),
+                             default_len='lattice' if args.config == 'stress' else 'hops', shard=(rank, world))
     od_warm = {k: v[:args.warmup_ods] for k, v in od.items()}
 
     import torch

@@ -227,10 +227,12 @@ def hop_distance(net, origins, dests, unreachable=-1, chunk=256, workers=1):
     return out
 
 
-def make_od_pairs(net, n_od, seed=2, default_len='hops', unreachable_len=20, workers=1):
+def make_od_pairs(net, n_od, seed=2, default_len='hops', unreachable_len=20, workers=1, shard=None):
     """OD pairs uniform over segments (o != d), start time codes U{0..2879}.
 
     default_len: 'hops' = BFS hop distance + 1 (exact, slow for many ODs), or an int constant.
+    shard = (rank, world): return only OD pairs rank, rank + world, ... of the n_od (the same pairs as slicing the
+    full result, without computing the other ranks' hop distances).
     Returns dict of int32 arrays: start, des, start_time, default_len.
     """
     rng = np.random.RandomState(seed)
@@ -239,6 +241,9 @@ def make_od_pairs(net, n_od, seed=2, default_len='hops', unreachable_len=20, wor
     d = rng.randint(0, n - 1, size=n_od)
     d = np.where(d >= o, d + 1, d)
     t = rng.randint(0, 2880, size=n_od)
+    if shard is not None:
+        o, d, t = o[shard[0]::shard[1]], d[shard[0]::shard[1]], t[shard[0]::shard[1]]
+        n_od = len(o)
     if default_len == 'hops':
         hops = hop_distance(net, o, d, workers=workers)
         dl = np.where(hops >= 0, hops + 1, unreachable_len)
