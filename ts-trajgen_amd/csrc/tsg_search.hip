@@ -184,8 +184,13 @@ __global__ void engine_init_pages_kernel(tsg_engine e) {
 
 __global__ __launch_bounds__(256) void cand_dis_kernel(EngineDev D, int superstep) {
   const int md = D.g.max_degree;
-  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (blockIdx.x == 0 && D.od.n_od > 0) engine_control_block(D);  // engine run (not the stand-alone scoring entry)
+  // the first workgroup only closes the books of the superstep (engine_control_block: the longest dependent chain
+  // of this launch, so it starts first and does nothing else); the others take the candidates
+  if (blockIdx.x == 0) {
+    if (D.od.n_od > 0) engine_control_block(D);  // engine run (not the stand-alone scoring entry)
+    return;
+  }
+  const long t = (long)(blockIdx.x - 1) * blockDim.x + threadIdx.x;
   const long q = t / md;  // position in the work list
   const int c = (int)(t % md);
   const int region = (int)(q / TSG_REGION_SLOTS), pos = (int)(q % TSG_REGION_SLOTS);
@@ -304,7 +309,7 @@ __global__ __launch_bounds__(256) void score_frontier_kernel(tsg_model m, Engine
 
 static void launch_cand_dis(const EngineDev& D, int superstep, hipStream_t s) {
   const long threads = (long)tsg_item_positions(D.e.slots) * D.g.max_degree;
-  hipLaunchKernelGGL(cand_dis_kernel, dim3(tsg_cdiv(threads, 256)), dim3(256), 0, s, D, superstep);
+  hipLaunchKernelGGL(cand_dis_kernel, dim3(tsg_cdiv(threads, 256) + 1), dim3(256), 0, s, D, superstep);
 }
 
 template <bool SPLIT>
