@@ -292,6 +292,13 @@ typedef struct tsg_engine {
  * small kernel).  The caller zeroes `shared_counters` itself when it is a separate array. */
 int tsg_engine_reset(const tsg_engine* e, const tsg_graph* g, void* stream);
 
+/* Function H on explicit pairs: out[i] = out_fc(cat[relu(emb_fc(cat[emb[from[i]], emb[to[i]]])), relu(dis_fc(dis[i]))]),
+ * the score BEFORE the softmax (DistanceGatFC.predict_cache, distance_gat_fc.py:118-134; DistanceGatFC.forward,
+ * :44-74, for a module in inference mode), from the factored tables pfrom / pto / hparams of tsg_model.
+ * from[i] < n_roads and to[i] < rows of pto are the caller's to guarantee (the Python wrapper checks them). */
+int tsg_h_pair_scores(const tsg_model* m, int32_t n, const int32_t* from, const int32_t* to, const float* dis,
+                      float* out, void* stream);
+
 /* Trajectories out of the expansion records of the searches (the path the reference carries in every SearchNode,
  * search.py:14-52: trace_loc / trace_tim, and returns at :291-296 / :421-424).  Request i names a search slot and
  * one of its expanded nodes (index into the slot's exp_meta); with last_rid[i] >= 0 one more point (last_rid[i],

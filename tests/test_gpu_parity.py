@@ -86,6 +86,12 @@ def test_g234_predict(road_model):
         h2 = road_model.function_h.predict_next(cs, dt, cd)
         np.testing.assert_allclose(g2.cpu().numpy()[0], c['g'], rtol=RTOL)
         np.testing.assert_allclose(h2.cpu().numpy()[0], c['h'], rtol=RTOL)
+        # scores before the softmax (predict_cache :118, inference-mode forward :44) and predict (:97)
+        fh = road_model.function_h
+        sc = fh.predict_cache(cs.flatten(), dt.repeat(cs.shape[1]), cd.flatten())
+        np.testing.assert_allclose(torch.softmax(sc, 0).cpu().numpy(), c['h'], rtol=RTOL)
+        assert torch.equal(sc, fh.forward(cs.flatten(), dt.repeat(cs.shape[1]), cd.flatten()))
+        np.testing.assert_allclose(fh.predict(cs, dt, cd).cpu().numpy()[0], c['h'], rtol=RTOL)
 
 
 def test_predict_batched_with_mask(road_model):

@@ -17,7 +17,7 @@ STATUS_UNTOUCHED, STATUS_REACHED, STATUS_FALLBACK, STATUS_OVERFLOW = 0, 1, 2, 0x
 EXPORTS = ('tsg_version', 'tsg_gemm_f32', 'tsg_gat_forward', 'tsg_gat_build_input', 'tsg_lstm_step_batched',
            'tsg_score_candidates', 'tsg_engine_reset', 'tsg_engine_run', 'tsg_engine_run_profiled', 'tsg_engine_graph_create', 'tsg_engine_graph_launch',
            'tsg_engine_graph_destroy', 'tsg_frontier_expand_select',
-           'tsg_score_frontier', 'tsg_rollout_run', 'tsg_reconstruct_paths')
+           'tsg_score_frontier', 'tsg_rollout_run', 'tsg_reconstruct_paths', 'tsg_h_pair_scores')
 
 _p = C.c_void_p
 _i32 = C.c_int32
@@ -123,6 +123,7 @@ def lib():
     L.tsg_frontier_expand_select.argtypes = [C.POINTER(Graph), C.POINTER(OdBatch), C.POINTER(Engine), _i32, _p]
     L.tsg_score_frontier.argtypes = [C.POINTER(Model), C.POINTER(Graph), C.POINTER(Engine), _i32, _p]
     L.tsg_reconstruct_paths.argtypes = [C.POINTER(Engine), _i32, _p, _p, _p, _p, _i32, _p, _p, _p, _p]
+    L.tsg_h_pair_scores.argtypes = [C.POINTER(Model), _i32, _p, _p, _p, _p, _p]
     L.tsg_rollout_run.argtypes = [C.POINTER(Model), C.POINTER(Graph), C.POINTER(Rollout), _i32, _p]
     for name in EXPORTS:
         getattr(L, name).restype = C.c_int

@@ -81,6 +81,25 @@ extern "C" int tsg_score_candidates(const tsg_model* m, const tsg_score_batch* b
   return 0;
 }
 
+// Function H on explicit (from, to, distance) triples: the score before the softmax (distance_gat_fc.py:118-134
+// predict_cache; :44-74 forward with the module in inference mode, where the node embeddings are the cached ones).
+__global__ void h_pair_scores_kernel(tsg_model m, int n, const int32_t* from, const int32_t* to, const float* dis,
+                                     float* out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = tsg_h_logit(m, from[i], to[i], dis[i]);
+}
+
+extern "C" int tsg_h_pair_scores(const tsg_model* m, int32_t n, const int32_t* from, const int32_t* to,
+                                 const float* dis, float* out, void* stream) {
+  if (!m || n < 0 || !m->pfrom || !m->pto || !m->hparams) return TSG_E_INVALID;
+  if (n == 0) return 0;
+  if (!from || !to || !dis || !out) return TSG_E_INVALID;
+  hipLaunchKernelGGL(h_pair_scores_kernel, dim3(tsg_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, *m, n, from, to,
+                     dis, out);
+  TSG_LAUNCH_CHECK();
+  return 0;
+}
+
 // Waves per workgroup of the two kernels whose waves run for very different times (a long ancestor chain, a long
 // pop chain): a workgroup gives its registers back only when its last wave ends, so one wave per workgroup
 // lets the next work item start as soon as ANY wave ends (scoring kernel: 130 -> 115 us per launch).

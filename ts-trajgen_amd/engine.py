@@ -213,6 +213,29 @@ class ModelTables(object):
         return prob, pg, ph
 
 
+    @torch.no_grad()
+    def h_pair_scores(self, from_node, to_node, distance):
+        """DistanceGatFC.predict_cache (distance_gat_fc.py:118-134): function H's score of (from, to, distance)
+        triples, before any softmax; 1-D tensors of equal length."""
+        L = _lib.lib()
+        dev = self.device
+        f = from_node.to(dev).to(torch.int32).reshape(-1).contiguous()
+        t = to_node.to(dev).to(torch.int32).reshape(-1).contiguous()
+        d = distance.to(dev).float().reshape(-1).contiguous()
+        n = int(f.numel())
+        if int(t.numel()) != n or int(d.numel()) != n:
+            raise ValueError('from_node, to_node and distance must have the same length')
+        out = torch.empty(n, dtype=torch.float32, device=dev)
+        if n == 0:
+            return out
+        if int(f.min()) < 0 or int(f.max()) >= self.c_model.n_roads or int(t.min()) < 0 or int(t.max()) >= self.n_nodes_h:
+            raise IndexError('node id outside the node embedding table')
+        with torch.cuda.device(dev):
+            _lib.check(L.tsg_h_pair_scores(C.byref(self.c_model), n, _lib.ptr(f), _lib.ptr(t), _lib.ptr(d),
+                                           _lib.ptr(out), _lib.current_stream()), 'tsg_h_pair_scores')
+        return out
+
+
 class GraphTables(object):
     """Device substrate of a road network in the layout of `tsg_graph`."""
 

@@ -82,5 +82,30 @@ class DistanceGatFC(nn.Module):
         loc = candidate_set[:, :1]
         return owner.predict_parts(loc, torch.zeros_like(loc), des, candidate_set, candidate_distance)[2]
 
-    def forward(self, *args, **kwargs):
-        raise NotImplementedError('training forward of function H is outside the generation path')
+    def _owner_tables(self, what):
+        from .generator_v4 import owner_of
+        owner = owner_of(self, 'function_h')
+        if owner is None:
+            raise RuntimeError('DistanceGatFC.%s runs through the device tables of its GeneratorV4: construct the '
+                               'module as GeneratorV4(config, data_feature).function_h' % what)
+        return owner.tables()
+
+    def predict_cache(self, from_node, to_node, distance):
+        """Score of (from, to, distance) triples before the softmax, on the cached node embeddings
+        (distance_gat_fc.py:118-134)."""
+        return self._owner_tables('predict_cache').h_pair_scores(from_node, to_node, distance)
+
+    def forward(self, from_node, to_node, distance):
+        """distance_gat_fc.py:44-74 for a module in inference mode: the reference re-encodes the graph on every call,
+        which gives the cached embeddings again as long as the parameters have not changed (the device tables are
+        rebuilt when they have).  The training-mode forward (dropout 0.6 inside the GAT, autograd) is not built."""
+        if self.training:
+            raise NotImplementedError('training forward/backward of function H is outside the generation path')
+        return self._owner_tables('forward').h_pair_scores(from_node, to_node, distance)
+
+    def predict(self, candidate_set, des, candidate_distance):
+        """softmax over the candidates of forward() (distance_gat_fc.py:97-116)."""
+        c = candidate_set.shape[1]
+        score = self.forward(candidate_set.flatten(), des.unsqueeze(1).repeat(1, c).flatten(),
+                             candidate_distance.flatten())
+        return torch.softmax(score.reshape(candidate_set.shape[0], c), dim=1)
