@@ -455,7 +455,7 @@ __global__ __launch_bounds__(256, 3) void lstm_layer_split_kernel(LstmArgs a) {
   const _Float16* wimg = reinterpret_cast<const _Float16*>(a.wt) + (size_t)coltile * nkt * (2 * BN * BK);
   unsigned* a_st = s_a[wave] + (lane >> 3) * 32 + (((lane & 7) ^ ((lane >> 3) & 7)) << 2);  // + j * 256 words
   const unsigned* a_ld = s_a[wave] + lr * 32;
-  tsg_u4 ma0, ma1, ma2, ma3, nb0, nb1, nb2, nb3;  // in flight: rows of the next tile but one... see the loop
+  tsg_u4 ma0, ma1, ma2, ma3, nb0, nb1, nb2, nb3;  // in flight: the rows of one k-tile (ma*) and the weights of one (nb*)
 #define TSG_GLOAD_ROWS(KT)                                                                                  \
   {                                                                                                         \
     const int k0_ = (KT) * BK;                                                                              \
