@@ -9,7 +9,7 @@
 // (row, unit) in the same accumulator register index and the cell update needs no cross-lane traffic.
 // A tile in LDS as [row][33] (pad 1: conflict-free ds_read_b32 of 32 rows at fixed k),
 // B tile as [k][128] (lanes read consecutive columns).
-#include "tsg_common.h"
+#include "tsg_engine_dev.h"
 
 #ifndef TSG_ABLATE
 #define TSG_ABLATE 0  // timing-only ablation builds (tools/build_variant.sh); 0 in the shipped library
@@ -120,6 +120,7 @@ struct LstmArgs {
   const int32_t* item_counts;  // engine mode: tsg_engine.item_counts
   const int32_t* pc;     // engine mode: tsg_engine.counters
   int slots;             // engine mode
+  int lstm_blocks;       // workgroups of the recurrence proper; the launch may carry cand_dis_block workgroups behind them
   const float* h_below;
   float* h;
   float* c;
@@ -391,7 +392,11 @@ extern "C" int tsg_debug_read_lstm_stamps(unsigned long long* out_host, int rese
 #endif
 
 template <bool LAYER0>
-__global__ __launch_bounds__(256, 3) void lstm_layer_split_kernel(LstmArgs a) {
+__global__ __launch_bounds__(256, 3) void lstm_layer_split_kernel(LstmArgs a, EngineDev D) {
+  if (LAYER0 && (int)blockIdx.x >= a.lstm_blocks) {  // the superstep's candidate distances ride on this launch
+    cand_dis_block(D, (int)blockIdx.x - a.lstm_blocks);
+    return;
+  }
 #if TSG_LSTM_STAMP
   long long lst_ = wall_clock64();
   long long lacc_[5] = {0, 0, 0, 0, 0};
@@ -610,7 +615,7 @@ static int check_model_dims(const tsg_model* m) {
 int tsg_launch_lstm_layer(const tsg_model* m, int layer, int max_rows, const int32_t* n_rows_dev, int n_rows_host,
                           const int64_t* prev_idx, const int64_t* out_idx, const int32_t* rid, const int32_t* tcode,
                           const tsg_engine* eng, const float* h_below, float* h, float* c,
-                          hipStream_t stream, int split) {
+                          hipStream_t stream, int split, const EngineDev* tail) {
   LstmArgs a;
   a.layer = layer;
   a.hp = m->hp;
@@ -639,11 +644,16 @@ int tsg_launch_lstm_layer(const tsg_model* m, int layer, int max_rows, const int
   if (max_rows <= 0) return 0;
   const int rowtiles = tsg_cdiv(max_rows, BM);
   const int grid = 8 * tsg_cdiv(rowtiles, 8) * (m->hp / 32);
+  a.lstm_blocks = grid;
   if (split) {
+    // `tail` (engine runs, layer 0 of the split form): the candidate-distance workgroups of the superstep go
+    // behind the recurrence's own, where the half-empty second round of this launch has room for them
+    EngineDev D = tail && layer == 0 ? *tail : EngineDev{};
+    const int extra = tail && layer == 0 ? cand_dis_blocks(tail->e, tail->g) : 0;
     if (layer == 0)
-      hipLaunchKernelGGL(lstm_layer_split_kernel<true>, dim3(grid), dim3(256), 0, stream, a);
+      hipLaunchKernelGGL(lstm_layer_split_kernel<true>, dim3(grid + extra), dim3(256), 0, stream, a, D);
     else
-      hipLaunchKernelGGL(lstm_layer_split_kernel<false>, dim3(grid), dim3(256), 0, stream, a);
+      hipLaunchKernelGGL(lstm_layer_split_kernel<false>, dim3(grid), dim3(256), 0, stream, a, D);
   } else if (layer == 0)
     hipLaunchKernelGGL(lstm_layer_kernel<true>, dim3(grid), dim3(256), 0, stream, a);
   else
@@ -659,5 +669,5 @@ extern "C" int tsg_lstm_step_batched(const tsg_model* m, const tsg_lstm_step* s,
   if (!s->prev_idx || !s->out_idx) return TSG_E_INVALID;
   if (s->layer == 0 && (!s->rid || !s->tcode)) return TSG_E_INVALID;
   return tsg_launch_lstm_layer(m, s->layer, s->n_rows_host, s->n_rows_dev, s->n_rows_host, s->prev_idx, s->out_idx,
-                               s->rid, s->tcode, nullptr, s->h_below, s->h, s->c, (hipStream_t)stream, 0);
+                               s->rid, s->tcode, nullptr, s->h_below, s->h, s->c, (hipStream_t)stream, 0, nullptr);
 }

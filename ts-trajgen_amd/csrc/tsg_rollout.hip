@@ -9,7 +9,7 @@
 int tsg_launch_lstm_layer(const tsg_model* m, int layer, int max_rows, const int32_t* n_rows_dev, int n_rows_host,
                           const int64_t* prev_idx, const int64_t* out_idx, const int32_t* rid, const int32_t* tcode,
                           const tsg_engine* eng, const float* h_below, float* h, float* c,
-                          hipStream_t stream, int split);
+                          hipStream_t stream, int split, const struct EngineDev* tail);
 
 struct RolloutDev {
   tsg_rollout r;
@@ -178,7 +178,7 @@ extern "C" int tsg_rollout_run(const tsg_model* m, const tsg_graph* g, const tsg
     hipLaunchKernelGGL(rollout_feed_kernel, grid_t, blk, 0, s, D);
     for (int l = 0; l < m->n_layers; ++l) {
       const int rc = tsg_launch_lstm_layer(m, l, r->n_traj, nullptr, r->n_traj, r->prev_idx, r->out_idx, r->rid,
-                                           r->tcode, nullptr, l > 0 ? r->h[l - 1] : nullptr, r->h[l], r->c[l], s, 0);
+                                           r->tcode, nullptr, l > 0 ? r->h[l - 1] : nullptr, r->h[l], r->c[l], s, 0, nullptr);
       if (rc) return rc;
     }
     switch (jt) {
