@@ -98,7 +98,7 @@ def pmc_traffic(kernel, lstm, rows_per_launch):
     with open(path) as f:
         js = json.load(f)
     names = {'frontier_kernel': 'frontier_kernel', 'score_frontier_kernel': 'score_frontier_kernel<4, true>',
-             'lstm_layer_kernel[l0]': 'lstm_layer_split_kernel<true>' if lstm == 'split' else 'lstm_layer_kernel<true>',
+             'lstm_layer_kernel[l0]': 'lstm_layer0_split_cand_kernel' if lstm == 'split' else 'lstm_layer_kernel<true>',
              'lstm_layer_kernel[l1]': 'lstm_layer_split_kernel<false>' if lstm == 'split' else 'lstm_layer_kernel<false>'}
     e = js.get(names.get(kernel, kernel))
     if not e:

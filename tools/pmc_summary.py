@@ -13,7 +13,8 @@ import json
 import sys
 from collections import defaultdict
 
-WIDE_READERS = ('score_frontier_kernel', 'lstm_layer_split_kernel', 'lstm_layer_kernel', 'gat_aggregate_kernel')
+WIDE_READERS = ('score_frontier_kernel', 'lstm_layer_split_kernel', 'lstm_layer0_split_cand_kernel', 'lstm_layer_kernel',
+                'gat_aggregate_kernel')
 
 
 def short(name):

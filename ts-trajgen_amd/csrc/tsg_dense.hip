@@ -392,11 +392,7 @@ extern "C" int tsg_debug_read_lstm_stamps(unsigned long long* out_host, int rese
 #endif
 
 template <bool LAYER0>
-__global__ __launch_bounds__(256, 3) void lstm_layer_split_kernel(LstmArgs a, EngineDev D) {
-  if (LAYER0 && (int)blockIdx.x >= a.lstm_blocks) {  // the superstep's candidate distances ride on this launch
-    cand_dis_block(D, (int)blockIdx.x - a.lstm_blocks);
-    return;
-  }
+__device__ __forceinline__ void lstm_layer_split_body(const LstmArgs& a) {
 #if TSG_LSTM_STAMP
   long long lst_ = wall_clock64();
   long long lacc_[5] = {0, 0, 0, 0, 0};
@@ -605,6 +601,21 @@ __global__ __launch_bounds__(256, 3) void lstm_layer_split_kernel(LstmArgs a, En
 #endif
 }
 
+template <bool LAYER0>
+__global__ __launch_bounds__(256, 3) void lstm_layer_split_kernel(LstmArgs a) {
+  lstm_layer_split_body<LAYER0>(a);
+}
+
+// Layer 0 of an engine superstep: the recurrence's own workgroups, then the superstep's candidate distances and
+// control step (cand_dis_block) as extra workgroups, which find room in the half-empty second round of this launch.
+__global__ __launch_bounds__(256, 3) void lstm_layer0_split_cand_kernel(LstmArgs a, EngineDev D) {
+  if ((int)blockIdx.x >= a.lstm_blocks) {
+    cand_dis_block(D, (int)blockIdx.x - a.lstm_blocks);
+    return;
+  }
+  lstm_layer_split_body<true>(a);
+}
+
 static int check_model_dims(const tsg_model* m) {
   if (!m) return TSG_E_INVALID;
   if (m->hp <= 0 || (m->hp % 64) != 0 || m->hp > 512) return TSG_E_INVALID;
@@ -648,12 +659,13 @@ int tsg_launch_lstm_layer(const tsg_model* m, int layer, int max_rows, const int
   if (split) {
     // `tail` (engine runs, layer 0 of the split form): the candidate-distance workgroups of the superstep go
     // behind the recurrence's own, where the half-empty second round of this launch has room for them
-    EngineDev D = tail && layer == 0 ? *tail : EngineDev{};
-    const int extra = tail && layer == 0 ? cand_dis_blocks(tail->e, tail->g) : 0;
-    if (layer == 0)
-      hipLaunchKernelGGL(lstm_layer_split_kernel<true>, dim3(grid + extra), dim3(256), 0, stream, a, D);
+    if (layer == 0 && tail)
+      hipLaunchKernelGGL(lstm_layer0_split_cand_kernel, dim3(grid + cand_dis_blocks(tail->e, tail->g)), dim3(256), 0,
+                         stream, a, *tail);
+    else if (layer == 0)
+      hipLaunchKernelGGL(lstm_layer_split_kernel<true>, dim3(grid), dim3(256), 0, stream, a);
     else
-      hipLaunchKernelGGL(lstm_layer_split_kernel<false>, dim3(grid), dim3(256), 0, stream, a, D);
+      hipLaunchKernelGGL(lstm_layer_split_kernel<false>, dim3(grid), dim3(256), 0, stream, a);
   } else if (layer == 0)
     hipLaunchKernelGGL(lstm_layer_kernel<true>, dim3(grid), dim3(256), 0, stream, a);
   else
