@@ -97,6 +97,24 @@ typedef struct tsg_gat_desc {
 
 int tsg_gat_forward(const tsg_gat_desc* d, void* stream);
 
+/* tsg_gat_forward without any allocation, by the caller or the library.  No counterpart in the reference: it
+ * is for callers that cannot allocate device memory (code under HIP-graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc), e.g. re-encoding a region graph (our_model_generate.py:62-83: ~100-1000
+ * regions) after a weight update.  Same descriptor, same kernels, same results as tsg_gat_forward, but the
+ * WORKSPACE fields of the descriptor (proj, s_src, s_trg, gmax, skip, w_skip_mean, w_att and their *_bytes)
+ * are ignored: the workspaces live in a file-scope device array of TSG_GAT_STATIC_SCRATCH_BYTES that every GPU
+ * the library runs on holds until the process ends.  Inputs (x, weights, CSR) and `out` are still the caller's.
+ *   - Limit: the workspaces, each rounded up to 256 bytes, must fit the array:
+ *       4 N NH F (proj) + 2 * 4 N NH (scores) + 256 (max) + 4 N outw (skip; 0 if skip_identity)
+ *       + 4 FIN F (folded skip weights; concat == 0 only) + 8 FIN NH (attention weights)  <=  8 MiB,
+ *     e.g. N <= 2 700 nodes at NH = 5, F = 128.  Larger graphs return TSG_E_LIMIT and launch nothing.
+ *   - The first call on a device looks up that device's address of the array (hipGetSymbolAddress); make it
+ *     once outside graph capture.  No call ever uses hipMalloc / hipFree or an allocating library routine.
+ *   - All calls on one GPU share the array: calls that may overlap on one GPU (different streams, threads or
+ *     processes' graphs replayed together) race; serialise them.  Nothing in it has to survive between calls. */
+#define TSG_GAT_STATIC_SCRATCH_BYTES (8u << 20)
+int tsg_gat_forward_static(const tsg_gat_desc* d, void* stream);
+
 /* GAT input features: x[n] = [lon_embed[nf[n][-2]], lat_embed[nf[n][-1]], nf[n][:-2]]
  * (generator/distance_gat_fc.py:191-197).  node_features [N][fraw] f32 (last two columns hold the
  * integer lon/lat grid cells), lon_embed [n_lon][gps], lat_embed [n_lat][gps], x [N][2*gps + fraw - 2].

@@ -1,0 +1,112 @@
+"""tsg_gat_forward_static (the entry point that allocates nothing, include/tsg.h) against tsg_gat_forward.
+
+Both run the same kernels; the static variant takes its workspaces from the library's file-scope device array
+instead of the descriptor.  Outputs must be bit-identical, on two calls in a row (the second on a smaller graph,
+so stale contents of the shared array would show), and a graph beyond the array's size must be refused."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _problem(torch, n, e, fin, nh, fo, concat, seed, dev):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn((n, fin), generator=g)
+    src = torch.randint(0, n, (e,), generator=g)
+    trg = torch.randint(0, n, (e,), generator=g)
+    trg[:3] = 0                                   # a busy target; node n-1 keeps in-degree 0 below
+    trg[trg == n - 1] = 0
+    par = {'w_proj_t': torch.randn((fin, nh * fo), generator=g) * 0.2,
+           'w_skip_t': torch.randn((fin, nh * fo), generator=g) * 0.2,
+           'a_src': torch.randn((nh, fo), generator=g) * 0.3, 'a_trg': torch.randn((nh, fo), generator=g) * 0.3,
+           'bias': torch.randn((nh * fo if concat else fo,), generator=g) * 0.1}
+    order = np.argsort(trg.numpy(), kind='stable')
+    in_ptr = np.zeros(n + 1, dtype=np.int32)
+    np.cumsum(np.bincount(trg.numpy(), minlength=n), out=in_ptr[1:])
+    in_src = src.numpy()[order].astype(np.int32)
+    t = {k: v.to(dev).contiguous() for k, v in par.items()}
+    t['x'] = x.to(dev).contiguous()
+    t['in_ptr'] = torch.from_numpy(in_ptr).to(dev)
+    t['in_src'] = torch.from_numpy(in_src).to(dev)
+    return t
+
+
+def _desc(_lib, t, n, e, fin, nh, fo, concat, out):
+    d = _lib.GatDesc()
+    d.n_nodes, d.n_edges, d.fin, d.heads, d.fout = n, e, fin, nh, fo
+    d.concat, d.skip_identity = int(concat), int(fin == fo)
+    d.x, d.w_proj_t, d.w_skip_t = _lib.ptr(t['x']), _lib.ptr(t['w_proj_t']), _lib.ptr(t['w_skip_t'])
+    d.a_src, d.a_trg, d.bias = _lib.ptr(t['a_src']), _lib.ptr(t['a_trg']), _lib.ptr(t['bias'])
+    d.in_ptr, d.in_src = _lib.ptr(t['in_ptr']), _lib.ptr(t['in_src'])
+    d.out, d.out_bytes = _lib.ptr(out), out.numel() * 4
+    return d
+
+
+def _both(torch, _lib, n, e, fin, nh, fo, concat, seed):
+    dev = 'cuda:0'
+    L = _lib.lib()
+    t = _problem(torch, n, e, fin, nh, fo, concat, seed, dev)
+    outw = nh * fo if concat else fo
+    stream = _lib.current_stream()
+    # existing entry point: caller-allocated workspaces
+    out_a = torch.full((n, outw), float('nan'), device=dev)
+    d = _desc(_lib, t, n, e, fin, nh, fo, concat, out_a)
+    ws = {'proj': torch.empty((n, nh * fo), device=dev), 's_src': torch.empty((n, nh), device=dev),
+          's_trg': torch.empty((n, nh), device=dev), 'gmax': torch.empty(1, device=dev),
+          'skip': torch.empty((n, outw), device=dev), 'w_skip_mean': torch.empty((fin, fo), device=dev),
+          'w_att': torch.empty((fin, 2 * nh), device=dev)}
+    d.proj, d.s_src, d.s_trg, d.gmax = (_lib.ptr(ws['proj']), _lib.ptr(ws['s_src']), _lib.ptr(ws['s_trg']),
+                                       _lib.ptr(ws['gmax']))
+    d.proj_bytes, d.s_bytes = ws['proj'].numel() * 4, ws['s_src'].numel() * 4
+    if fin != fo:
+        d.skip, d.skip_bytes = _lib.ptr(ws['skip']), ws['skip'].numel() * 4
+        if not concat:
+            d.w_skip_mean, d.w_skip_mean_bytes = _lib.ptr(ws['w_skip_mean']), ws['w_skip_mean'].numel() * 4
+    d.w_att, d.w_att_bytes = _lib.ptr(ws['w_att']), ws['w_att'].numel() * 4
+    _lib.check(L.tsg_gat_forward(C.byref(d), stream), 'tsg_gat_forward')
+    # the variant that allocates nothing: workspace fields left NULL / 0
+    out_b = torch.full((n, outw), float('nan'), device=dev)
+    ds = _desc(_lib, t, n, e, fin, nh, fo, concat, out_b)
+    before = torch.cuda.memory_allocated(dev)
+    _lib.check(L.tsg_gat_forward_static(C.byref(ds), stream), 'tsg_gat_forward_static')
+    torch.cuda.synchronize()
+    assert torch.cuda.memory_allocated(dev) == before
+    a, b = out_a.cpu(), out_b.cpu()
+    assert torch.isfinite(a).all() and torch.isfinite(b).all()
+    assert torch.equal(a, b), 'max abs diff %g' % float((a - b).abs().max())
+    return a
+
+
+def test_static_scratch_gat_matches_gat_forward_twice_in_a_row():
+    import torch
+    from ts_trajgen_amd import _lib
+    # region-model shape of the path (our_model_generate.py:62-83): raw features, 5 heads x 128, head mean
+    big = _both(torch, _lib, n=900, e=5200, fin=128 + 12, nh=5, fo=128, concat=False, seed=11)
+    # second call, smaller graph, other shape class (concat, generic F): stale scratch contents must not matter
+    small = _both(torch, _lib, n=77, e=310, fin=12, nh=3, fo=40, concat=True, seed=12)
+    # and the first problem again: identical to its first run
+    again = _both(torch, _lib, n=900, e=5200, fin=128 + 12, nh=5, fo=128, concat=False, seed=11)
+    assert torch.equal(big, again)
+    assert small.shape == (77, 120)
+
+
+def test_static_scratch_gat_identity_skip():
+    import torch
+    from ts_trajgen_amd import _lib
+    _both(torch, _lib, n=65, e=200, fin=32, nh=5, fo=32, concat=False, seed=13)     # FIN == F branch (gat.py:94-97)
+
+
+def test_static_scratch_gat_rejects_graphs_beyond_the_array():
+    import torch
+    from ts_trajgen_amd import _lib
+    L = _lib.lib()
+    n, e, fin, nh, fo = 40000, 8, 30, 5, 256          # proj alone is 205 MB
+    t = _problem(torch, 16, e, fin, nh, fo, False, 14, 'cuda:0')
+    out = torch.zeros((16, fo), device='cuda:0')
+    d = _desc(_lib, t, n, e, fin, nh, fo, False, out)
+    d.out_bytes = n * fo * 4                           # claim a large enough output: the size check comes first
+    assert L.tsg_gat_forward_static(C.byref(d), _lib.current_stream()) == -3      # TSG_E_LIMIT, nothing launched
+    torch.cuda.synchronize()
+    assert float(out.abs().sum()) == 0.0

@@ -13,8 +13,9 @@ TSG_MAX_LAYERS = 4
 TSG_MAX_DEGREE = 64
 TSG_H_HIDDEN = 10
 STATUS_UNTOUCHED, STATUS_REACHED, STATUS_FALLBACK, STATUS_OVERFLOW = 0, 1, 2, 0x100
+GAT_STATIC_SCRATCH_BYTES = 8 << 20     # TSG_GAT_STATIC_SCRATCH_BYTES
 
-EXPORTS = ('tsg_version', 'tsg_gemm_f32', 'tsg_gat_forward', 'tsg_gat_build_input', 'tsg_lstm_step_batched',
+EXPORTS = ('tsg_version', 'tsg_gemm_f32', 'tsg_gat_forward', 'tsg_gat_forward_static', 'tsg_gat_build_input', 'tsg_lstm_step_batched',
            'tsg_score_candidates', 'tsg_engine_reset', 'tsg_engine_run', 'tsg_engine_run_profiled', 'tsg_engine_graph_create', 'tsg_engine_graph_launch',
            'tsg_engine_graph_destroy', 'tsg_frontier_expand_select',
            'tsg_score_frontier', 'tsg_rollout_run', 'tsg_reconstruct_paths', 'tsg_h_pair_scores')
@@ -108,6 +109,7 @@ def lib():
     L.tsg_version.restype = C.c_int
     L.tsg_gemm_f32.argtypes = [_p, C.c_int, _p, C.c_int, _p, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p]
     L.tsg_gat_forward.argtypes = [C.POINTER(GatDesc), _p]
+    L.tsg_gat_forward_static.argtypes = [C.POINTER(GatDesc), _p]
     L.tsg_gat_build_input.argtypes = [_p, C.c_int, C.c_int, _p, C.c_int, _p, C.c_int, C.c_int, _p, _p]
     L.tsg_lstm_step_batched.argtypes = [C.POINTER(Model), C.POINTER(LstmStep), _p]
     L.tsg_score_candidates.argtypes = [C.POINTER(Model), C.POINTER(ScoreBatch), _p]

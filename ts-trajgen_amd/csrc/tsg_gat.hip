@@ -6,6 +6,8 @@
 //      source rows + skip projection + head mean/concat + bias + ELU, all in one pass.
 // Incoming edges are visited in their original COO order, so the per-target sums are accumulated
 // in the same order as the reference's sequential scatter_add_.
+#include <mutex>
+
 #include "tsg_common.h"
 
 extern "C" int tsg_gemm_f32(const float* A, int lda, const float* Bt, int ldb, const float* bias, float* C, int ldc,
@@ -243,7 +245,7 @@ __global__ __launch_bounds__(256) void gat_aggregate_kernel(tsg_gat_desc d) {
   }
 }
 
-extern "C" int tsg_gat_forward(const tsg_gat_desc* d, void* stream) {
+static int gat_forward_impl(const tsg_gat_desc* d, void* stream) {
   if (!d) return TSG_E_INVALID;
   if (d->n_nodes <= 0 || d->n_edges < 0 || d->fin <= 0 || d->heads <= 0 || d->fout <= 0) return TSG_E_INVALID;
   if (d->heads > 16 || d->fout > 64 * GAT_MAXJ) return TSG_E_LIMIT;
@@ -303,6 +305,76 @@ extern "C" int tsg_gat_forward(const tsg_gat_desc* d, void* stream) {
     hipLaunchKernelGGL(gat_aggregate_kernel<0>, agrid, dim3(256), 0, s, *d);
   TSG_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int tsg_gat_forward(const tsg_gat_desc* d, void* stream) { return gat_forward_impl(d, stream); }
+
+// ------------------------------------------------------------------------------------ no-allocation variant
+// tsg_gat_forward for callers that cannot allocate (include/tsg.h): the workspaces of the encoder (projection,
+// node scores, global max, skip product, folded skip / attention weights) are carved out of one file-scope
+// device array instead of coming in through the descriptor.  Every GPU holds its own copy of the array at its
+// own address: the address is looked up once per device (hipGetSymbolAddress, with that device current) and
+// kept; host code never passes the array's name to a kernel.
+static __device__ __align__(256) unsigned char scratch[TSG_GAT_STATIC_SCRATCH_BYTES];
+
+#define TSG_MAX_DEVICES 64
+static void* g_scratch_ptr[TSG_MAX_DEVICES];
+static std::mutex g_scratch_mu;
+
+static int scratch_of_current_device(unsigned char** out) {
+  int dev = -1;
+  TSG_HIP_TRY(hipGetDevice(&dev));
+  if (dev < 0 || dev >= TSG_MAX_DEVICES) return TSG_E_LIMIT;
+  std::lock_guard<std::mutex> lock(g_scratch_mu);
+  if (!g_scratch_ptr[dev]) {
+    void* p = nullptr;
+    TSG_HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+    if (!p) return TSG_E_INVALID;
+    g_scratch_ptr[dev] = p;
+  }
+  *out = static_cast<unsigned char*>(g_scratch_ptr[dev]);
+  return 0;
+}
+
+static inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+extern "C" int tsg_gat_forward_static(const tsg_gat_desc* d, void* stream) {
+  if (!d) return TSG_E_INVALID;
+  if (d->n_nodes <= 0 || d->n_edges < 0 || d->fin <= 0 || d->heads <= 0 || d->fout <= 0) return TSG_E_INVALID;
+  if (d->heads > 16 || d->fout > 64 * GAT_MAXJ) return TSG_E_LIMIT;
+  const size_t N = (size_t)d->n_nodes, HF = (size_t)d->heads * d->fout;
+  const size_t outw = d->concat ? HF : (size_t)d->fout;
+  // the same workspaces as tsg_gat_desc documents, laid out back to back (256-byte aligned)
+  const size_t proj_b = N * HF * 4, s_b = N * d->heads * 4;
+  const size_t skip_b = d->skip_identity ? 0 : N * outw * 4;
+  const size_t wmean_b = (d->skip_identity || d->concat) ? 0 : (size_t)d->fin * d->fout * 4;
+  const size_t watt_b = (size_t)d->fin * 2 * d->heads * 4;
+  size_t off = 0;
+  const size_t o_proj = off;  off += align256(proj_b);
+  const size_t o_ssrc = off;  off += align256(s_b);
+  const size_t o_strg = off;  off += align256(s_b);
+  const size_t o_gmax = off;  off += 256;
+  const size_t o_skip = off;  off += align256(skip_b);
+  const size_t o_wmean = off; off += align256(wmean_b);
+  const size_t o_watt = off;  off += align256(watt_b);
+  if (off > (size_t)TSG_GAT_STATIC_SCRATCH_BYTES) return TSG_E_LIMIT;  // graph too large for the static scratch
+  unsigned char* base = nullptr;
+  const int rc = scratch_of_current_device(&base);
+  if (rc) return rc;
+  tsg_gat_desc w = *d;
+  w.proj = reinterpret_cast<float*>(base + o_proj);
+  w.s_src = reinterpret_cast<float*>(base + o_ssrc);
+  w.s_trg = reinterpret_cast<float*>(base + o_strg);
+  w.gmax = reinterpret_cast<float*>(base + o_gmax);
+  w.proj_bytes = proj_b;
+  w.s_bytes = s_b;
+  w.skip = skip_b ? reinterpret_cast<float*>(base + o_skip) : nullptr;
+  w.skip_bytes = skip_b;
+  w.w_skip_mean = wmean_b ? reinterpret_cast<float*>(base + o_wmean) : nullptr;
+  w.w_skip_mean_bytes = wmean_b;
+  w.w_att = reinterpret_cast<float*>(base + o_watt);
+  w.w_att_bytes = watt_b;
+  return gat_forward_impl(&w, stream);
 }
 
 __global__ __launch_bounds__(256) void gat_build_input_kernel(const float* __restrict__ nf, int n_nodes, int fraw,
