@@ -5,13 +5,17 @@
 
 One "step" = one pass of the whole path (frontier -> LSTM cell on MFMA -> candidate scoring, repeated
 until every search ends) over one batch of synthetic OD pairs per GPU, inputs resident in HBM.
-Workload at N = 1: BASELINE.json configs[1] (Porto-scale synthetic road graph, N = 11 095 segments,
-E = 25 000 turn edges, 64k OD pairs, BJ model dims, random-init weights, max_step 5000).  For N > 1
-every rank gets its own 64k OD pairs (weak scaling; OD pairs shard with no data-path collective) and one
-RCCL all-gather collects the padded trajectories inside the timed region.
+Default workload: BASELINE.json configs[2], the configuration the north-star target is quoted on: the
+BJ-scale synthetic road graph (N = 40 306 segments, E = 100 000 turn edges), BJ model dims, random-init
+weights, max_step 5000, 1 048 576 OD pairs over 8 GPUs = 131 072 OD pairs per GPU per step, dealt
+od_id % world.  Every rank runs its share (weak scaling: at N = 8 the job IS configs[2] as written, at
+N = 1 it is one rank's share of it; OD pairs shard with no data-path collective) and one RCCL all-gather
+collects the padded trajectories inside the timed region.  `--total-ods T` fixes the whole job instead
+(strong scaling); `--config porto` is BASELINE.json configs[1] (65 536 OD pairs per GPU).
 Prints ONE JSON line on rank 0 (metric: generated trajectories/sec) with `roofline` for the dominant
-kernel (durations from HIP events around every launch of sampled supersteps, on the launch stream) and
-`cpu_baseline` (the CPU oracle, i.e. a port of the reference algorithm, on a bounded OD sample).
+kernel (durations from HIP events around every launch of sampled supersteps, on the launch stream),
+`cpu_baseline` (the CPU oracle, i.e. a port of the reference algorithm, on a fixed OD sample, one search per
+host core, run before the GPU is touched) and `two_stage` (BASELINE.json configs[3] on the same GPU).
 """
 import argparse
 import json
@@ -42,8 +46,11 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=1)
     ap.add_argument('--warmup', type=int, default=1)
-    ap.add_argument('--config', default='porto', choices=['grid', 'porto', 'bj', 'stress'])
-    ap.add_argument('--ods', type=int, default=65536, help='OD pairs per GPU per step')
+    ap.add_argument('--config', default='bj', choices=['grid', 'porto', 'bj', 'stress'])
+    ap.add_argument('--ods', type=int, default=0,
+                    help='OD pairs per GPU per step (0 = the config\'s own: bj 131072 = 1M / 8, others 65536)')
+    ap.add_argument('--total-ods', type=int, default=0,
+                    help='OD pairs of the whole job per step, dealt od_id %% world (strong scaling); overrides --ods')
     ap.add_argument('--warmup-ods', type=int, default=4096, help='OD pairs per GPU in a warm-up step')
     ap.add_argument('--max-step', type=int, default=5000)
     ap.add_argument('--slots', type=int, default=0, help='searches in flight per GPU (0 = auto)')
@@ -54,7 +61,11 @@ def parse():
     ap.add_argument('--profile-every', type=int, default=8, help='event-bracket every k-th chunk of supersteps')
     ap.add_argument('--lstm', default='split', choices=['split', 'fp32'],
                     help='recurrent matmul: split-f16 three-pass matrix-core form (fp32-grade products) or plain fp32 MFMA')
-    ap.add_argument('--cpu-seconds', type=float, default=20.0, help='CPU baseline budget (0 = skip)')
+    ap.add_argument('--cpu-seconds', type=float, default=25.0,
+                    help='CPU baseline: no new OD pair is started after this many seconds (0 = skip)')
+    ap.add_argument('--cpu-ods', type=int, default=64, help='CPU baseline: the fixed sample = first k OD pairs')
+    ap.add_argument('--two-stage-ods', type=int, default=16384,
+                    help='OD pairs of the two-stage sub-record (configs[3], N = 1 only; 0 = skip)')
     return ap.parse_args()
 
 
@@ -69,21 +80,33 @@ def build_network(name):
     return synth.bj_scale_network(), 'BJ-scale synthetic road graph N=40306 E=100000'
 
 
-def build_model(net, device, gat_dim=None):
+def build_model_cpu(net, gat_dim=None):
+    """The generator with the reference constructors' random init under torch.manual_seed(0), still on the CPU
+    (nothing here touches the GPU: the CPU baseline forks its workers from this state)."""
     import copy
     import torch
     from ts_trajgen_amd.generator import GeneratorV4
     cfg = copy.deepcopy(BJ_DIMS)
     if gat_dim:
         cfg['function_h']['embed_dim'] = gat_dim
-    cfg['function_g']['device'] = device
-    cfg['function_h']['device'] = device
+    cfg['function_g']['device'] = 'cpu'
+    cfg['function_h']['device'] = 'cpu'
     torch.manual_seed(0)
     model = GeneratorV4(config=cfg, data_feature=net.data_feature(torch))
-    model = model.to(device)
-    model.function_h.node_features = model.function_h.node_features.to(device)
     model.train(False)
     return model, cfg
+
+
+def to_device(model, cfg, device):
+    cfg['function_g']['device'] = device
+    cfg['function_h']['device'] = device
+    model = model.to(device)
+    model.function_h.device = device
+    model.function_h.gat_encoder.device = device
+    model.function_h.Apt = model.function_h.Apt.to(device)
+    model.function_h.node_features = model.function_h.node_features.to(device)
+    model.train(False)
+    return model
 
 
 def pmc_traffic(kernel, lstm, rows_per_launch):
@@ -172,11 +195,56 @@ def measured_peaks(device):
     return out
 
 
-def cpu_baseline(net, model, cfg, od, budget_s, max_step):
-    """The CPU oracle (port of search.py:240-424 + generator_v4.py:56-72) on the first ODs of the workload."""
+_CPU = {}
+
+
+def _cpu_worker_init():
     import torch
+    torch.set_num_threads(1)
+    # one warm-up search per worker (lazy initialisation, first-touch of the forked pages)
     from oracle import search as osr
+    o = _CPU
+    osr.astar_search(o['om'], o['net'].adjacent_list, o['net'].rid_gps, o['net'].road_length, o['rtd'],
+                     [int(o['od']['start'][0])], [int(o['od']['start_time'][0])], int(o['od']['des'][0]),
+                     int(o['od']['default_len'][0]), 30)
+
+
+def _cpu_worker(i):
+    from oracle import search as osr
+    o = _CPU
+    if time.time() - o['t0'] > o['budget']:
+        return None
+    st = osr.SearchStats()
+    osr.astar_search(o['om'], o['net'].adjacent_list, o['net'].rid_gps, o['net'].road_length, o['rtd'],
+                     [int(o['od']['start'][i])], [int(o['od']['start_time'][i])], int(o['od']['des'][i]),
+                     int(o['od']['default_len'][i]), o['max_step'], stats=st)
+    return st.steps
+
+
+def cpu_model_name():
+    try:
+        with open('/proc/cpuinfo') as f:
+            for line in f:
+                if line.startswith('model name'):
+                    return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
+def cpu_baseline(net, model, cfg, od, budget_s, max_step, n_sample):
+    """The CPU oracle (port of search.py:240-424 + generator_v4.py:56-72: the reference's algorithm, one OD pair at a
+    time, the LSTM re-run over the whole prefix at every expansion) on a FIXED sample: the first `n_sample` OD pairs
+    of the workload, same max_step, one search per host core (forked workers, torch at one thread each: the
+    reference's batch-1 model call does not use more), after one warm-up search per worker.  Runs before this
+    process touches the GPU (the workers are forks).  No new OD pair is started after `budget_s` seconds, so the
+    default bench finishes in minutes whatever the host; the sample actually completed is reported."""
+    import multiprocessing as mp
+    import torch
     from oracle.model import OracleGenerator
+    workers = max(1, min(int(os.environ.get('OMP_NUM_THREADS', '0') or 0) or 16, os.cpu_count() or 1, 16))
+    prev_threads = torch.get_num_threads()
+    torch.set_num_threads(1)      # the parent stays single-threaded until the workers are forked
     g_state = {k: v.detach().cpu() for k, v in model.function_g.state_dict().items()}
     h_state = {k: v.detach().cpu() for k, v in model.function_h.state_dict().items()}
     ei = np.stack([net.adj_mx.row, net.adj_mx.col]).astype(np.int64)
@@ -184,22 +252,82 @@ def cpu_baseline(net, model, cfg, od, budget_s, max_step):
                          cfg['function_h']['num_of_heads'], cfg['function_h']['embed_dim'],
                          cfg['function_g']['lstm_layer_num'])
     om.setup_node_emb()
-    rtd = net.road_time_distribution.astype(int)
-    t0 = time.time()
-    done = 0
-    steps = 0
-    while done < len(od['des']) and (time.time() - t0 < budget_s or done < 1):
-        st = osr.SearchStats()
-        osr.astar_search(om, net.adjacent_list, net.rid_gps, net.road_length, rtd, [int(od['start'][done])],
-                         [int(od['start_time'][done])], int(od['des'][done]), int(od['default_len'][done]),
-                         max_step, stats=st)
-        steps += st.steps
-        done += 1
-    dt = time.time() - t0
-    return {'value': done / dt, 'unit': 'trajectories/s', 'cores': int(torch.get_num_threads()), 'kind': 'port',
-            'sample': 'first %d OD pairs of the same workload (%d expansions) in %.1f s, torch-CPU fp32'
-                      % (done, steps, dt),
+    n_sample = min(n_sample, len(od['des']))
+    _CPU.update({'om': om, 'net': net, 'rtd': net.road_time_distribution.astype(int), 'od': od,
+                 'max_step': max_step, 'budget': budget_s, 't0': 0.0})
+    with mp.get_context('fork').Pool(workers, initializer=_cpu_worker_init) as pool:
+        pool.map(_cpu_noop, range(workers * 4))          # every worker is up and warm before the clock starts
+        t0 = time.time()
+        # the budget is checked in the workers against the parent's clock: fork copies _CPU, so the start time
+        # travels with every task instead
+        res = pool.map(_cpu_worker_timed, [(i, t0) for i in range(n_sample)], chunksize=1)
+        dt = time.time() - t0
+    torch.set_num_threads(prev_threads)
+    _CPU.clear()
+    done = [r for r in res if r is not None]
+    steps = int(sum(done))
+    return {'value': len(done) / dt, 'unit': 'trajectories/s', 'cores': workers, 'kind': 'port',
+            'sample': 'first %d OD pairs of the same workload (fixed sample of %d; %d expansions) in %.1f s: one '
+                      'search per core on %d forked workers, torch-CPU fp32 at 1 thread each, 1 warm-up search per '
+                      'worker, max_step %d' % (len(done), n_sample, steps, dt, workers, max_step),
+            'cpu_model': cpu_model_name(), 'host_cpus': os.cpu_count(), 'torch_threads_per_worker': 1,
             'expansions_per_s': steps / dt}
+
+
+def _cpu_noop(_):
+    time.sleep(0.01)
+    return 0
+
+
+def _cpu_worker_timed(arg):
+    i, t0 = arg
+    _CPU['t0'] = t0
+    return _cpu_worker(i)
+
+
+def two_stage_record(net, od, device, max_step):
+    """BASELINE.json configs[3]: two-stage generation (region-level A*, then road-level A* leg by leg) on the
+    Porto-scale graph with a 10 x 10 region partition, region model 128/32/128; whole-job trajectories/s."""
+    import torch
+    from ts_trajgen_amd import dataset as ds
+    from ts_trajgen_amd import synth
+    from ts_trajgen_amd.generator import GeneratorV4
+    from ts_trajgen_amd.search import DoubleLayerSearcher
+    n_od = len(od['des'])
+    reg = synth.region_tables(net, tiles=10)
+    road, cfg = build_model_cpu(net)
+    road = to_device(road, cfg, device)
+    road.function_h._setup_node_emb()
+    feats = ds.region_features_from_road_emb(road.function_h.node_emb_feature[:net.num_roads], reg['rid2region'],
+                                             reg['num_regions'])
+    feats = torch.cat([feats, torch.zeros((1, feats.shape[1]), device=feats.device)], dim=0)
+    r = reg['num_regions']
+    rcfg = ds._gen_config((128, 32, 128, 128, 10, 5), device, True)          # our_model_generate.py:62-83
+    rdf = {'road_num': r + 1, 'time_size': 2881, 'road_pad': r, 'time_pad': 2880, 'adj_mx': reg['region_adj_mx'],
+           'node_features': feats.cpu(), 'img_width': 52, 'img_height': 43}
+    torch.manual_seed(1)
+    region = GeneratorV4(config=rcfg, data_feature=rdf).to(device)
+    region.function_h.node_features = region.function_h.node_features.to(device)
+    region.train(False)
+    s = DoubleLayerSearcher(device, net.adjacent_list, net.rid_gps, net.road_length, reg['region_adjacent_list'],
+                            reg['region_dist'], reg['region_transfer_freq'], reg['rid2region'], reg['region2rid'],
+                            net.road_time_distribution, reg['region_time_distribution'])
+    w = slice(0, 256)
+    s.generate(region, road, od['start'][w], od['start_time'][w], od['des'][w], od['default_len'][w],
+               max_step=max_step, seeds=list(range(256)))
+    torch.cuda.synchronize()
+    t0 = time.time()
+    locs, tims, flags = s.generate(region, road, od['start'], od['start_time'], od['des'], od['default_len'],
+                                   max_step=max_step, seeds=list(range(n_od)))
+    torch.cuda.synchronize()
+    dt = time.time() - t0
+    reached = sum(int(l[-1] == d) for l, d in zip(locs, od['des']))
+    return {'value': n_od / dt, 'unit': 'trajectories/s', 'od_pairs': n_od, 'seconds': dt,
+            'workload': 'two-stage: Porto-scale graph N=%d, %d regions (10 x 10 tiling), region model 128/32/128, '
+                        'per-OD RandomState(od_id), max_step %d' % (net.num_roads, r, max_step),
+            'reached_frac': reached / n_od, 'rounds': s.last_stats['rounds'],
+            'road_expansions_per_od': s.last_stats['road_expansions'] / n_od,
+            'gpu_busy_frac': s.last_stats.get('gpu_busy_frac')}
 
 
 def main():
@@ -209,11 +337,26 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     from ts_trajgen_amd import synth
     net, net_name = build_network(args.config)
+    scaling = 'weak'
+    if args.total_ods > 0:
+        n_total, scaling = args.total_ods, 'strong'
+    else:
+        per_gpu = args.ods if args.ods > 0 else (131072 if args.config == 'bj' else 256 if args.config == 'grid' else 65536)
+        n_total = per_gpu * world
     # OD pairs for all ranks (seeded), sharded round-robin by index; BFS default_len before the GPU is touched
-    n_total = args.ods * world
     od = synth.make_od_pairs(net, n_total, seed=2, workers=max(1, min(16, (os.cpu_count() or 1) // world)),
                              default_len='lattice' if args.config == 'stress' else 'hops', shard=(rank, world))
+    n_local = len(od['des'])
     od_warm = {k: v[:args.warmup_ods] for k, v in od.items()}
+    net2 = od2 = None
+    if world == 1 and args.two_stage_ods > 0:      # configs[3] sub-record: its OD pairs, also before the GPU is touched
+        net2 = synth.porto_scale_network()
+        od2 = synth.make_od_pairs(net2, args.two_stage_ods, seed=7, workers=max(1, min(16, os.cpu_count() or 1)))
+
+    model, cfg = build_model_cpu(net, gat_dim=128 if args.config == 'stress' else None)
+    cpu = None
+    if world == 1 and args.cpu_seconds > 0:       # forks its workers: must come before the GPU is touched
+        cpu = cpu_baseline(net, model, cfg, od, args.cpu_seconds, args.max_step, args.cpu_ods)
 
     import torch
     import torch.distributed as dist
@@ -222,7 +365,7 @@ def main():
     if world > 1:
         dist.init_process_group('nccl', device_id=torch.device(device))
     from ts_trajgen_amd.search import Searcher
-    model, cfg = build_model(net, device, gat_dim=128 if args.config == 'stress' else None)
+    model = to_device(model, cfg, device)
     searcher = Searcher(device, net.adjacent_list, net.rid_gps, net.road_length, net.road_time_distribution)
     searcher.state_format = 1 if args.lstm == 'split' else 0
     tables = model.tables()
@@ -233,11 +376,13 @@ def main():
     page = AStarEngine.bytes_per_page(tables)
     pps = (1 + args.max_step + 63) // 64
     free_b, _total = torch.cuda.mem_get_info(torch.device(device))
-    budget = int(free_b * 0.93) - (2 * args.lmax + 8) * 4 * args.ods
+    budget = int(free_b * 0.93) - (2 * args.lmax + 8) * 4 * n_local
+    if world > 1:
+        budget -= (2 * args.lmax + 8) * 4 * n_local * (world + 1)      # the packed rows and the gathered result
     slots = args.slots
     if slots <= 0:
         slots = int(budget // (fixed + pps * page / args.oversub))
-        slots = min(slots, 32768, args.ods)
+        slots = min(slots, 32768, n_local)
         # LSTM grid: 8 workgroups per 128 searches, 768 resident at a time -> whole waves of workgroups at 12 288
         slots = slots // 12288 * 12288 if slots >= 12288 else max(128, slots // 1024 * 1024 if slots >= 1024 else slots // 128 * 128)
     pool_pages = min(slots * pps, int((budget - slots * fixed) // page))
@@ -248,11 +393,9 @@ def main():
                                 max_step=args.max_step, slots=slots, lmax=args.lmax, return_device=True,
                                 profile_every=profile_every, pool_pages=pool_pages, ramp_steps=ramp)
         if world > 1:   # the single exchange step of the path: collect the padded trajectories (RCCL over xGMI)
-            packed = torch.cat([res['rid'], res['time'], res['len'].unsqueeze(1), res['status'].unsqueeze(1)], dim=1)
-            gathered = torch.empty((world * packed.shape[0], packed.shape[1]), dtype=packed.dtype,
-                                   device=packed.device)
-            dist.all_gather_into_tensor(gathered, packed)
-            res['gathered'] = gathered
+            from ts_trajgen_amd.distributed import gather_results, pack_rows
+            n_call = n_total if o is od else len(o['des']) * world
+            res['gathered'] = gather_results(pack_rows(res, args.lmax), n_call, args.lmax, rank, world)
         return res
 
     def sync():
@@ -274,15 +417,14 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    n_done = args.steps * args.ods * world
+    n_done = args.steps * n_total
     status = res['status'].cpu().numpy()
     exp_total = sum(s['expansions'] for s in stats)
+    tot = torch.tensor([exp_total, sum(s['model_evals'] for s in stats), sum(s['items'] for s in stats)],
+                       dtype=torch.float64, device=device)
     if world > 1:
-        t = torch.tensor([exp_total], dtype=torch.float64, device=device)
-        dist.all_reduce(t)
-        exp_all = float(t.item())
-    else:
-        exp_all = float(exp_total)
+        dist.all_reduce(tot)
+    exp_all, evals_all, items_all = [float(x) for x in tot.tolist()]
 
     if rank == 0:
         hp, nl = tables.hp, tables.n_layers
@@ -310,20 +452,30 @@ def main():
                 flops = rows_per_launch * 2.0 * 4 * hp * K
                 # split form: three f16 matrix-core passes per algorithmic product -> a third of the dense f16 peak
                 peak = PEAK_F16_MFMA_TFLOPS / 3.0 if args.lstm == 'split' else PEAK_F32_MFMA_TFLOPS
-                k.update({'bound': 'mfma', 'achieved': flops / (avg_ms * 1e-3) / 1e12, 'peak': peak,
-                          'unit': 'TFLOP/s'})
+                mfma = {'achieved': flops / (avg_ms * 1e-3) / 1e12, 'peak': peak, 'unit': 'TFLOP/s'}
+                mfma['frac'] = mfma['achieved'] / peak
+                # algorithmic HBM bytes per row: previous h and c of the layer in, new h and c out (4 rows of
+                # 4 Hp bytes); layer 0 also gathers the pre-multiplied input rows xproj[rid] and tproj[tcode]
+                # (4 * 4 Hp bytes each), layers above read the new h of the layer below (4 Hp)
+                per = 4 * 4 * hp + (2 * 16 * hp if l == 0 else 4 * hp)
+                hbm = {'achieved': rows_per_launch * per / (avg_ms * 1e-3) / 1e9, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s'}
+                hbm['frac'] = hbm['achieved'] / PEAK_HBM_GBS
+                binding = hbm if hbm['frac'] > mfma['frac'] else mfma      # the roofline the kernel is nearer to
+                k.update({'bound': 'hbm' if binding is hbm else 'mfma', 'achieved': binding['achieved'],
+                          'peak': binding['peak'], 'unit': binding['unit'], 'mfma': mfma, 'hbm': hbm,
+                          'algorithmic_bytes_per_row': per, 'algorithmic_flop_per_row': 2.0 * 4 * hp * K})
             elif nm.startswith('score'):
                 # own + ancestor top-layer h rows, gathered out_fc rows (+bias), factored H tables,
                 # lon/lat, CSR row, item record, cand_lp write
                 per = 4 * hp * (1 + avg_L) + avg_C * (4 * (hp + 1) + 80 + 16 + 8) + 40 + 16 + 32
                 byts = rows_per_launch * scored_frac * per
                 k.update({'bound': 'hbm', 'achieved': byts / (avg_ms * 1e-3) / 1e9, 'peak': PEAK_HBM_GBS,
-                          'unit': 'GB/s'})
+                          'unit': 'GB/s', 'algorithmic_bytes_per_scored_row': per})
             else:
                 per = 40 * avg_C + 32 + 32 + 128      # SURVEY 8(d) frontier bytes + item + slot state
                 byts = rows_per_launch * per
                 k.update({'bound': 'hbm', 'achieved': byts / (avg_ms * 1e-3) / 1e9, 'peak': PEAK_HBM_GBS,
-                          'unit': 'GB/s'})
+                          'unit': 'GB/s', 'note': 'latency-bound: chains of dependent 8-32 byte accesses'})
             k['frac'] = k['achieved'] / k['peak']
             kern[nm] = k
         dom = max(kern, key=lambda n: kern[n]['share']) if kern else None
@@ -341,24 +493,41 @@ def main():
                 peaks['f16_gemm_TFLOPs'] / 3.0 if args.lstm == 'split' and 'f16_gemm_TFLOPs' in peaks else None)
             k['measured_peak'] = ref      # this box: device-to-device copy / a third of an 8192^3 f16 matmul
             k['frac_of_measured'] = k['achieved'] / ref if ref else None
-        cpu = None
-        if world == 1 and args.cpu_seconds > 0:
-            cpu = cpu_baseline(net, model, cfg, od, args.cpu_seconds, args.max_step)
+        two = None
+        if world == 1 and args.two_stage_ods > 0:
+            del res
+            searcher._engines.clear()         # give the page pool back before the two-stage engines are sized
+            torch.cuda.empty_cache()
+            two = two_stage_record(net2, od2, device, args.max_step)
+        recurrence = ('split-f16 x3: every fp32 operand as f16 major + f16 minor (22 significant bits), three f16 '
+                      'matrix-core passes, fp32 accumulation; hidden states stored in that form, cell states fp32'
+                      if args.lstm == 'split' else 'fp32 matrix cores (v_mfma_f32_32x32x2_f32)')
         out = {
             'metric': 'generated trajectories/sec (road-level A*)', 'value': n_done / dt, 'unit': 'trajectories/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt * 1e3 / args.steps,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': '%s, %d OD pairs per GPU, BJ model dims (hidden 256, 2-layer LSTM, GAT 5x256), '
-                                   'random-init weights, max_step %d' % (net_name, args.ods, args.max_step),
-                       'od_pairs_per_gpu': args.ods, 'slots_in_flight': slots, 'state_pool_pages': pool_pages,
-                       'state_pool_gb': pool_pages * page / 1e9, 'lstm': args.lstm, 'parallelism': 'od-shard x%d' % world},
+            'higher_is_better': True, 'scaling': scaling, 'vs_baseline': None,
+            'dtype': 'f32' if args.lstm != 'split' else 'f32 (recurrence operands: split-f16, 22 bits; fp32 accumulate)',
+            'data': 'synthetic',
+            'config': {'workload': '%s, %d OD pairs per step over %d GPU(s) dealt od_id %% world (%d per GPU), BJ model '
+                                   'dims (hidden 256, 2-layer LSTM, GAT 5x256), random-init weights, max_step %d'
+                                   % (net_name, n_total, world, n_local, args.max_step),
+                       'baseline_config': {'bj': 'configs[2]', 'porto': 'configs[1]', 'grid': 'configs[0]',
+                                           'stress': 'configs[4]'}[args.config],
+                       'od_pairs_per_step': n_total, 'od_pairs_per_gpu': n_local, 'slots_in_flight': slots,
+                       'state_pool_pages': pool_pages, 'state_pool_gb': pool_pages * page / 1e9, 'lstm': args.lstm,
+                       'recurrence': recurrence, 'parallelism': 'od-shard x%d' % world},
             'expansions_per_s': exp_all / dt, 'expansions_per_od': exp_all / n_done,
+            # `expansions` counts every `step` of search.py:420, including the ones the frontier kernel closes without
+            # a model call (single-successor, gated-out and futile expansions: identical results); what ran the
+            # recurrence is work_items, what ran the whole model (recurrence + scoring) is model_evals
+            'work_items_per_s': items_all / dt, 'model_evals_per_s': evals_all / dt,
             'reached_frac': float((status & 0xff == 1).mean()), 'fallback_frac': float((status & 0xff == 2).mean()),
             'avg_prefix_len_scored': avg_L, 'avg_candidates_scored': avg_C,
             'supersteps': int(sum(s['supersteps'] for s in stats)), 'work_items': int(items),
             'page_waits': int(sum(s['page_waits'] for s in stats)), 'restarts': int(sum(s['restarts'] for s in stats)),
             'min_free_pages': int(min(s['min_free_pages'] for s in stats)),
             'roofline': roofline, 'kernels': kern, 'measured_peaks': peaks, 'gat_encoder': gat, 'cpu_baseline': cpu,
+            'two_stage': two,
         }
         print(json.dumps(out))
     if world > 1:

@@ -17,7 +17,12 @@
  *     synchronisation, no global mutable state, re-entrant across streams/devices.
  *   - Return value: 0 on success, a negative TSG_E_* code or -(hipError_t) - 1000 otherwise.
  *     No C++ exception crosses the boundary.
- *   - fp32 arithmetic, int32 ids/time codes, fp64 only inside the geodesic distance.
+ *   - Arithmetic: fp32 (int32 ids/time codes, fp64 only inside the geodesic distance), with ONE documented
+ *     exception: the engine's default recurrence (tsg_engine.state_format == 1, what Searcher uses unless told
+ *     otherwise) carries every LSTM operand as two f16 numbers (22 significant bits, two fewer than fp32), runs
+ *     three f16 matrix-core passes per product with fp32 accumulation, and stores hidden states in that form;
+ *     gates use v_exp_f32 / v_rcp_f32.  state_format == 0 is the plain fp32 matrix-core path.  Both forms give the
+ *     oracle's trajectories on every golden and full-size test; a near-tie (|df| < 1e-5) may fall differently.
  */
 #ifndef TSG_H_
 #define TSG_H_
@@ -168,7 +173,8 @@ typedef struct tsg_lstm_step {
   const float* h_below;    /* [rows][Hp] (layer >= 1): new hidden of layer-1 */
   float* h;                /* [rows][Hp] this layer's hidden states (read prev, write out) */
   float* c;                /* [rows][Hp] this layer's cell states */
-  size_t state_rows;       /* rows in h / c, for bounds checking of host-known indices */
+  size_t state_rows;       /* rows in h / c: a row whose out_idx is outside [0, state_rows) is skipped, a prev_idx
+                              outside it counts as "no previous state" (checked on the device; 0 = unchecked) */
 } tsg_lstm_step;
 
 int tsg_lstm_step_batched(const tsg_model* m, const tsg_lstm_step* s, void* stream);
@@ -176,7 +182,9 @@ int tsg_lstm_step_batched(const tsg_model* m, const tsg_lstm_step* s, void* stre
 /* ------------------------------------------------------------------------------------------
  * Candidate scoring for explicit (prefix, candidates, distances) rows: the drop-in for
  * GeneratorV4.predict (generator/generator_v4.py:56-72) == softmax((1-w1) softmax(G) + w1 softmax(H)).
- * Row i attends over the top-layer hidden rows chain[chain_ptr[i] .. chain_ptr[i+1]) (last = query),
+ * Row i attends over the top-layer hidden rows chain[chain_ptr[i] .. chain_ptr[i+1]) (last = query; a row may be
+ * listed more than once, e.g. an all-zero row standing for the padded positions of a masked batch, which the
+ * reference keeps in the attention softmax, function_g_fc.py:31-35),
  * scores candidates cand[cand_ptr[i] .. cand_ptr[i+1]) with distances dis[...] towards des[i] and
  * writes prob[...] (and, if non-NULL, the separate G and H softmaxes).  <= TSG_MAX_DEGREE candidates.
  * ------------------------------------------------------------------------------------------ */
@@ -192,6 +200,9 @@ typedef struct tsg_score_batch {
   float* prob;              /* out, same layout as cand */
   float* prob_g;            /* out or NULL */
   float* prob_h;            /* out or NULL */
+  float* logit_g;           /* out or NULL: function G's candidate scores BEFORE its softmax, out_fc(attn)[cand]
+                               (FunctionGFC.forward, function_g_fc.py:184-187) */
+  float* logit_h;           /* out or NULL: function H's scores before its softmax (distance_gat_fc.py:129-134) */
 } tsg_score_batch;
 
 int tsg_score_candidates(const tsg_model* m, const tsg_score_batch* b, void* stream);
@@ -249,7 +260,8 @@ typedef struct tsg_engine {
   /* workspaces (caller-allocated); *_bytes are checked against the dims above */
   int32_t* slot_state;  size_t slot_state_bytes;  /* [B][40] int32 */
   uint64_t* heap;       size_t heap_bytes;        /* [B][heap_cap] {float prio; int32 node} */
-  uint32_t* table;      size_t table_bytes;       /* [B][n_roads] rid -> (generation<<20 | node+1), zeroed by caller */
+  uint32_t* table;      size_t table_bytes;       /* [B][n_roads] rid -> (generation << 20 | node index); generation 0 =
+                                                     never seen, so tsg_engine_reset zeroes it once per OD batch */
   int32_t* nodes;       size_t nodes_bytes;       /* [B][node_cap][8] int32 */
   int32_t* exp_meta;    size_t exp_meta_bytes;    /* [B][exp_cap][4] {parent, rid, tcode, depth} */
   int32_t* exp_up;      size_t exp_up_bytes;      /* [n_pages*64][64]: exp_up[row][i] = state row of the (i+1)-th ancestor
@@ -299,7 +311,7 @@ typedef struct tsg_engine {
                                                      the SAME tsg_od_batch share this array: one OD queue */
   int32_t* counters;    size_t counters_bytes;    /* [16] state-page control of THIS engine: 0 ring head, 1 ring tail,
                                                      2 tail snapshot, 3-5 the same for `retry`, 6 waits, 7 restarts,
-                                                     8 restart level, 9 plane of item_counts just filled, 10 unused, 11 superstep,
+                                                     8 restart level, 9 plane of item_counts just filled, 10 reserved, 11 superstep,
                                                      12 fewest free pages seen, 13 admission quota, 14 restart budget.
                                                      shared_counters: 2 next OD, 3 finished ODs, 4 total expansions,
                                                      6 error flag.  Per-slot statistics live in slot_state words
@@ -316,6 +328,14 @@ int tsg_engine_reset(const tsg_engine* e, const tsg_graph* g, void* stream);
  * from[i] < n_roads and to[i] < rows of pto are the caller's to guarantee (the Python wrapper checks them). */
 int tsg_h_pair_scores(const tsg_model* m, int32_t n, const int32_t* from, const int32_t* to, const float* dis,
                       float* out, void* stream);
+
+/* The candidate distance on explicit pairs: out_m[i] = WGS-84 inverse geodesic (Vincenty, fp64, metres) between
+ * rows a[i] and b[i] of `geo` ([n_rows][4] as tsg_graph.geo); -1 for an index outside the table.  Replaces
+ * geopy.distance.distance((lat, lon), (lat, lon)) at search.py:355-356 (the engine feeds the model
+ * kilometres * 10 = out_m / 100 as f32); the engine computes the same function inside its supersteps, this
+ * entry point exposes it for callers of GeneratorV4.predict and for the parity test. */
+int tsg_geodesic_pairs(const double* geo, int32_t n_rows, int32_t n, const int32_t* a, const int32_t* b,
+                       double* out_m, void* stream);
 
 /* Trajectories out of the expansion records of the searches (the path the reference carries in every SearchNode,
  * search.py:14-52: trace_loc / trace_tim, and returns at :291-296 / :421-424).  Request i names a search slot and

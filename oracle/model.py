@@ -115,6 +115,22 @@ def g_attn_hidden(sd, trace_loc, trace_tim, num_layers):
     return (w.unsqueeze(1) * hs).sum(dim=0)                                          # :35
 
 
+def g_attn_hidden_masked(sd, trace_loc, trace_tim, num_layers, padded_len):
+    """The same for one row of a padded batch WITH trace_mask (function_g_fc.py:162-180): the packed LSTM runs
+    over the row's real positions, pad_packed_sequence re-pads its output with ZERO rows up to the longest row
+    of the batch (`padded_len`), the query is the last real state, and -- the masked_fill of :33 being assigned
+    to `mask`, not to the weights -- the softmax of :34 runs over all `padded_len` positions, the zero rows
+    included (logit 0)."""
+    loc = torch.as_tensor(trace_loc, dtype=torch.long)
+    tim = torch.as_tensor(trace_tim, dtype=torch.long)
+    x = torch.cat([sd['road_emb.weight'][loc], sd['time_emb.weight'][tim]], dim=1)
+    hs = lstm_forward(sd, x, num_layers)
+    q = hs[-1]                                                                       # :173-177
+    key = torch.cat([hs, torch.zeros((padded_len - hs.shape[0], hs.shape[1]))], dim=0)   # :167
+    w = torch.softmax(key @ q, dim=0)                                                # :31,34 (mask has no effect)
+    return (w.unsqueeze(1) * key).sum(dim=0)                                         # :35
+
+
 def g_scores(sd, trace_loc, trace_tim, cand, num_layers):
     """function_g_fc.py:184-186: full-vocabulary FC then gather the candidates' logits."""
     a = g_attn_hidden(sd, trace_loc, trace_tim, num_layers)
@@ -148,6 +164,21 @@ class OracleGenerator(object):
     def predict_g(self, trace_loc, trace_tim, cand):
         c = torch.as_tensor(cand, dtype=torch.long)
         return torch.softmax(g_scores(self.g, trace_loc, trace_tim, c, self.lstm_layers), dim=0)  # :221
+
+    def g_logits(self, trace_loc, trace_tim, cand, padded_len=None):
+        """FunctionGFC.forward (function_g_fc.py:138-187): candidate scores before the softmax; with `padded_len`
+        the row sits in a masked batch padded to that length."""
+        c = torch.as_tensor(cand, dtype=torch.long)
+        if padded_len is None:
+            return g_scores(self.g, trace_loc, trace_tim, c, self.lstm_layers)
+        a = g_attn_hidden_masked(self.g, trace_loc, trace_tim, self.lstm_layers, padded_len)
+        return F.linear(a, self.g['out_fc.weight'], self.g['out_fc.bias'])[c]
+
+    def predict_masked_row(self, trace_loc, trace_tim, des, cand, dis, padded_len):
+        """GeneratorV4.predict for one row of a masked batch padded to `padded_len` (see g_attn_hidden_masked)."""
+        g = torch.softmax(self.g_logits(trace_loc, trace_tim, cand, padded_len), dim=0)
+        h = self.predict_h(cand, des, dis)
+        return torch.softmax(torch.add((1 - self.w1) * g, self.w1 * h), dim=0), g
 
     def predict_h(self, cand, des, dis):
         c = torch.as_tensor(cand, dtype=torch.long)

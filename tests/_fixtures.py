@@ -114,3 +114,24 @@ def build_generator(world, device):
     model.function_h.node_features = model.function_h.node_features.to(device)
     model.train(False)
     return model
+
+
+def classify_traj(res, i, loc, tim, pop_rid, pop_prio, near_tie=1e-5):
+    """How search i of a result dict (with its pop log) compares with the expected (loc, tim) and the expected
+    pop trace: 'exact', or 'near-tie' when the FIRST diverging pop differs in priority by < near_tie (relative
+    to max(1, |priority|)): the documented exception of the north star.  Anything else raises: a different
+    trajectory is never accepted without that proof."""
+    n = int(res['len'][i])
+    if res['rid'][i, :n].tolist() == [int(x) for x in loc] and res['time'][i, :n].tolist() == [int(x) for x in tim]:
+        return 'exact'
+    k = int(res['poplog_n'][i])
+    assert k <= res['poplog_rid'].shape[1], 'pop log of search %d truncated: raise poplog_cap' % i
+    got_r = res['poplog_rid'][i, :k].tolist()
+    got_p = res['poplog_prio'][i, :k].tolist()
+    for j in range(min(len(got_r), len(pop_rid))):
+        if got_r[j] != int(pop_rid[j]):
+            want = float(pop_prio[j])
+            assert abs(got_p[j] - want) < near_tie * max(1.0, abs(want)), \
+                'search %d diverges at pop %d by %g (not a near-tie)' % (i, j, got_p[j] - want)
+            return 'near-tie'
+    raise AssertionError('search %d: same pop order but a different trajectory' % i)

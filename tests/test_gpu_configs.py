@@ -90,14 +90,12 @@ def test_config3_two_stage_porto_scale():
     small = 120
     l2, t2, f2 = s.generate(region_model, road_model, od['start'][sub], od['start_time'][sub], od['des'][sub],
                             od['default_len'][sub], max_step=small, seeds=sub)
-    same = 0
     for i in sub:
         loc, tim, fl = osearch.double_layer_astar_search(o_region, o_road, tables, int(od['start'][i]),
                                                          int(od['start_time'][i]), int(od['des'][i]),
                                                          int(od['default_len'][i]), max_step=small,
                                                          rng=np.random.RandomState(i))
-        same += int([int(x) for x in loc] == l2[i] and [int(x) for x in tim] == t2[i] and fl == f2[i])
-    assert same >= len(sub) - 1, same
+        assert [int(x) for x in loc] == l2[i] and [int(x) for x in tim] == t2[i] and fl == f2[i], i
 
 
 def test_config4_stress_city():

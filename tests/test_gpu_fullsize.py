@@ -93,30 +93,25 @@ def test_config0_trajectories_match_oracle(grid, state_format):
                      slots=8, poplog_cap=max_step + 8)
     om = _oracle(net, model, cfg)
     rtd = net.road_time_distribution.astype(int)
-    exact = near = 0
+    kinds = []
     for i in range(len(od['des'])):
         st = osr.SearchStats()
         loc, tim = osr.astar_search(om, net.adjacent_list, net.rid_gps, net.road_length, rtd, [int(od['start'][i])],
                                     [int(od['start_time'][i])], int(od['des'][i]), int(od['default_len'][i]),
                                     max_step, stats=st)
-        n = int(res['len'][i])
-        if res['rid'][i, :n].tolist() == loc and res['time'][i, :n].tolist() == tim:
-            exact += 1
-            assert int(res['steps'][i]) == st.steps
-            continue
-        # documented near-tie: the first diverging pop differs in priority by < 1e-5
-        pops = st.pops
-        k = int(res['poplog_n'][i])
-        got_r = res['poplog_rid'][i, :k].tolist()
-        got_p = res['poplog_prio'][i, :k].tolist()
-        for j in range(min(k, len(pops))):
-            if got_r[j] != pops[j][0]:
-                assert abs(got_p[j] - pops[j][1]) < 1e-5 * max(1.0, abs(pops[j][1])), (i, j)
-                near += 1
-                break
-        else:
-            raise AssertionError('OD %d: same pop order, different trajectory' % i)
+        kinds.append(_same_or_near_tie(res, i, loc, tim, st))
+    exact, near = kinds.count('exact'), kinds.count('near-tie')
     assert exact >= len(od['des']) - 2, (exact, near)
+
+
+def _same_or_near_tie(res, i, loc, tim, st):
+    """Search i against the oracle's (loc, tim) and pop trace: 'exact' (then the step counts agree too) or a
+    documented near-tie (first diverging pop within 1e-5 in priority); anything else raises."""
+    from tests._fixtures import classify_traj
+    kind = classify_traj(res, i, loc, tim, [p[0] for p in st.pops], [p[1] for p in st.pops])
+    if kind == 'exact':
+        assert int(res['steps'][i]) == st.steps
+    return kind
 
 
 def _check_properties(net, od, res, max_step, lmax):
@@ -185,16 +180,21 @@ def test_config1_split_recurrence_against_fp32(porto):
     plain fp32 MFMA recurrence (summation order differs, so isolated near-ties may flip)."""
     from ts_trajgen_amd.search import Searcher
     net, model, cfg, od = porto
+    from tests._fixtures import classify_traj
     sub = slice(0, 512)
     out = []
     for fmt in (1, 0):
         s = Searcher(DEV, net.adjacent_list, net.rid_gps, net.road_length, net.road_time_distribution)
         s.state_format = fmt
         out.append(s.generate(model, od['start'][sub], od['start_time'][sub], od['des'][sub], od['default_len'][sub],
-                              max_step=1000, slots=512, lmax=256))
-    same = sum(int(torch.equal(out[0]['rid'][i], out[1]['rid'][i]) and torch.equal(out[0]['time'][i], out[1]['time'][i]))
-               for i in range(512))
-    assert same >= 512 - 5, same
+                              max_step=1000, slots=512, lmax=256, poplog_cap=1100))
+    a, b = out
+    kinds = []
+    for i in range(512):
+        n, k = int(b['len'][i]), int(b['poplog_n'][i])
+        kinds.append(classify_traj(a, i, b['rid'][i, :n].tolist(), b['time'][i, :n].tolist(),
+                                   b['poplog_rid'][i, :k].tolist(), b['poplog_prio'][i, :k].tolist()))
+    assert kinds.count('exact') >= 512 - 5, kinds.count('near-tie')      # every other one is a proven near-tie
 
 
 def test_config1_state_page_pool_under_pressure(porto):
@@ -242,3 +242,70 @@ def test_config1_work_list_over_several_regions(porto):
         assert torch.equal(ref[k], got[k]), k
     half = len(od['des'])
     assert torch.equal(got['rid'][:half], got['rid'][half:])       # the same OD pair twice: the same trajectory
+
+
+# ---- BASELINE.json configs[2]: the BJ-scale graph (N = 40 306, E = 100 000), the config the target is quoted on
+@pytest.fixture(scope='module')
+def bj():
+    from ts_trajgen_amd import synth
+    net = synth.bj_scale_network()
+    assert net.num_roads == 40306 and len(net.adj_mx.row) == 100000
+    model, cfg = _model(net)
+    od = synth.make_od_pairs(net, 2048, seed=2, workers=1)
+    return net, model, cfg, od
+
+
+def test_config2_bj_scale_properties_batch_independence_and_pool_pressure(bj):
+    """Full max_step on the BJ-scale graph: per-trajectory properties; the same OD pairs with another number of
+    searches in flight, and on a state-page pool far below the worst case (waits and restarts), bit for bit."""
+    from ts_trajgen_amd.search import Searcher
+    net, model, cfg, od = bj
+    max_step, lmax = 5000, 256
+    s = Searcher(DEV, net.adjacent_list, net.rid_gps, net.road_length, net.road_time_distribution)
+    res = s.generate(model, od['start'], od['start_time'], od['des'], od['default_len'], max_step=max_step,
+                     slots=1024, lmax=lmax)
+    assert s.last_stats['page_waits'] == 0 and s.last_stats['restarts'] == 0
+    _check_properties(net, od, res, max_step, lmax)
+    st = res['status'].numpy()
+    assert (st == 1).sum() > 0 and (st == 2).sum() > 0
+    assert float(res['steps'].float().mean()) > 2000        # nearly breadth-first at this size (BASELINE.md section 2)
+    sub = slice(0, 640)
+    args = (model, od['start'][sub], od['start_time'][sub], od['des'][sub], od['default_len'][sub])
+    res2 = s.generate(*args, max_step=max_step, slots=256, lmax=lmax)
+    for k in ('rid', 'time', 'len', 'status', 'steps'):
+        assert torch.equal(res[k][sub], res2[k]), k
+    pps = (1 + max_step + 63) // 64
+    res3 = s.generate(*args, max_step=max_step, slots=512, lmax=lmax, pool_pages=40 * pps, ramp_steps=500)
+    st3 = dict(s.last_stats)
+    for k in ('rid', 'time', 'len', 'status', 'steps'):
+        assert torch.equal(res[k][sub], res3[k]), k
+    assert st3['min_free_pages'] < 40 * pps // 4 and st3['page_waits'] > 0, st3
+
+
+def test_config2_bj_scale_against_oracle(bj):
+    """A few OD pairs of the BJ-scale workload against the CPU oracle (bounded max_step: the oracle re-runs the
+    LSTM over the whole prefix at every expansion), both recurrence forms; embeddings within 1e-4 relative."""
+    from oracle import search as osr
+    from ts_trajgen_amd.search import Searcher
+    net, model, cfg, od = bj
+    om = _oracle(net, model, cfg)
+    model.function_h._setup_node_emb()
+    got = model.function_h.node_emb_feature.cpu().numpy()
+    want = om.node_emb.numpy() if torch.is_tensor(om.node_emb) else np.asarray(om.node_emb)
+    assert np.abs(got - want).max() <= RTOL * np.abs(want).max()
+    rtd = net.road_time_distribution.astype(int)
+    n, max_step = 8, 150
+    want_tr = []
+    for i in range(n):
+        stt = osr.SearchStats()
+        loc, tim = osr.astar_search(om, net.adjacent_list, net.rid_gps, net.road_length, rtd, [int(od['start'][i])],
+                                    [int(od['start_time'][i])], int(od['des'][i]), int(od['default_len'][i]),
+                                    max_step, stats=stt)
+        want_tr.append((loc, tim, stt))
+    for fmt in (1, 0):
+        s = Searcher(DEV, net.adjacent_list, net.rid_gps, net.road_length, net.road_time_distribution)
+        s.state_format = fmt
+        res = s.generate(model, od['start'][:n], od['start_time'][:n], od['des'][:n], od['default_len'][:n],
+                         max_step=max_step, slots=8, poplog_cap=max_step + 8)
+        for i in range(n):
+            _same_or_near_tie(res, i, *want_tr[i])

@@ -50,6 +50,28 @@ def test_g234_predict(road):
         np.testing.assert_allclose(p, c['p'], rtol=RTOL, atol=1e-7)
 
 
+def test_g10_masked_batch_and_logits(road):
+    """The reference's padded batch with trace_mask: the padded (zero) positions stay in the attention softmax
+    (function_g_fc.py:33 assigns the masked_fill to `mask`); and FunctionGFC.forward's candidate logits."""
+    m = road.oracle_model()
+    g10 = load_json('g10_masked_batch.json')
+    assert len(g10['batches']) >= 2
+    shorter = 0
+    for b in g10['batches']:
+        T = len(b['loc'][0])
+        for i in range(len(b['loc'])):
+            n = int(sum(b['mask'][i]))
+            shorter += int(n < T)
+            loc, tim = b['loc'][i][:n], b['tim'][i][:n]
+            p, g = m.predict_masked_row(loc, tim, b['des'][i], b['cand'][i], b['dis'][i], T)
+            np.testing.assert_allclose(m.g_logits(loc, tim, b['cand'][i], T).numpy(), b['g_score'][i], rtol=RTOL, atol=1e-6)
+            np.testing.assert_allclose(g.numpy(), b['g'][i], rtol=RTOL, atol=1e-7)
+            np.testing.assert_allclose(p.numpy(), b['p'][i], rtol=RTOL, atol=1e-7)
+    assert shorter > 0
+    for c in g10['logits']:
+        np.testing.assert_allclose(m.g_logits(c['loc'], c['tim'], c['cand']).numpy(), c['g_score'], rtol=RTOL, atol=1e-6)
+
+
 def _check_search_case(got_loc, got_tim, stats, c):
     assert got_loc == c['loc']
     assert got_tim == c['tim']

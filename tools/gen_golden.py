@@ -469,8 +469,122 @@ def gen_beam_search(net, model):
           len(cases) - len(ok), '; index bounds', sorted(set(c['index_bound'] for c in ok)))
 
 
+# ----------------------------------------------------------------------------- G10: masked batches, logits before the softmax
+def gen_masked_batch(net, model):
+    """GeneratorV4.predict / FunctionGFC.predict_g / FunctionGFC.forward for a padded (B, T) batch WITH trace_mask
+    (function_g_fc.py:162-180: packed LSTM, last valid hidden state as the query, attention over every position
+    of the re-padded LSTM output -- the masked_fill of :33 is assigned to `mask`, so padded (zero) rows stay in
+    the softmax), and FunctionGFC.forward's candidate logits for the unmasked one-row cases."""
+    cases = json.load(open(os.path.join(OUT, 'g234_predict.json')))['cases']
+    counts = [len(c['cand']) for c in cases]
+    out = {'batches': [], 'logits': []}
+    with torch.no_grad():
+        for ncand in sorted(set(counts)):
+            grp = [c for c in cases if len(c['cand']) == ncand]
+            if len(grp) < 2:
+                continue
+            T = max(len(c['loc']) for c in grp)
+            loc = torch.full((len(grp), T), net.num_roads, dtype=torch.long)     # road_pad / time_pad in the padding
+            tim = torch.full((len(grp), T), 2880, dtype=torch.long)
+            mask = torch.zeros((len(grp), T), dtype=torch.long)
+            for i, c in enumerate(grp):
+                loc[i, :len(c['loc'])] = torch.LongTensor(c['loc'])
+                tim[i, :len(c['tim'])] = torch.LongTensor(c['tim'])
+                mask[i, :len(c['loc'])] = 1
+            cs = torch.LongTensor([c['cand'] for c in grp])
+            cd = torch.FloatTensor([c['dis'] for c in grp])
+            dt = torch.LongTensor([c['des'] for c in grp])
+            p = model.predict(trace_loc=loc, trace_time=tim, des=dt, candidate_set=cs, candidate_dis=cd,
+                              trace_mask=mask)
+            g = model.function_g.predict_g(loc, tim, dt, cs, cd, trace_mask=mask)
+            score = model.function_g.forward(loc, tim, dt, cs, cd, trace_mask=mask, train=False)
+            mix = model.forward(trace_loc=loc, trace_time=tim, des=dt, candidate_set=cs, candidate_dis=cd,
+                                trace_mask=mask)
+            out['batches'].append({'loc': loc.tolist(), 'tim': tim.tolist(), 'mask': mask.tolist(),
+                                   'cand': cs.tolist(), 'dis': cd.tolist(), 'des': dt.tolist(),
+                                   'p': p.tolist(), 'g': g.tolist(), 'g_score': score.tolist(), 'mix': mix.tolist()})
+        for c in cases[:12]:
+            tl = torch.LongTensor(c['loc']).unsqueeze(0)
+            tt = torch.LongTensor(c['tim']).unsqueeze(0)
+            cs = torch.LongTensor(c['cand']).unsqueeze(0)
+            cd = torch.FloatTensor(c['dis']).unsqueeze(0)
+            dt = torch.LongTensor([c['des']])
+            score = model.function_g.forward(tl, tt, dt, cs, cd, None, False)
+            out['logits'].append({'loc': c['loc'], 'tim': c['tim'], 'cand': c['cand'], 'dis': c['dis'],
+                                  'des': c['des'], 'g_score': score.squeeze(0).tolist()})
+    with open(os.path.join(OUT, 'g10_masked_batch.json'), 'w') as f:
+        json.dump(out, f)
+    print('G10 done', len(out['batches']), 'batches', [len(b['loc']) for b in out['batches']])
+
+
+# ----------------------------------------------------------------------------- G11: the reference at BJ dims on configs[0]
+BJ_CFG = {   # our_model_generate.py:41-59
+    'function_g': {'road_emb_size': 256, 'time_emb_size': 50, 'hidden_size': 256, 'dropout_p': 0.6,
+                   'lstm_layer_num': 2, 'pretrain_road_rep': None, 'dis_weight': 0.5, 'device': 'cpu'},
+    'function_h': {'embed_dim': 256, 'gps_emb_dim': 10, 'num_of_heads': 5, 'concat': False, 'device': 'cpu',
+                   'distance_mode': 'l2'},
+    'dis_weight': 0.45,
+}
+
+
+def _bj_worker(args):
+    lo, hi = args
+    torch.set_num_threads(1)
+    net = synth.street_grid_network(32)
+    torch.manual_seed(0)
+    model = GeneratorV4(config=BJ_CFG, data_feature=net.data_feature(torch))
+    model.train(False)
+    od = synth.make_od_pairs(net, 256, seed=2)
+    ref_search.PriorityQueue = RecordingPQ
+    searcher = ref_search.Searcher('cpu', net.adjacent_list, net.rid_gps, net.road_length,
+                                   net.road_time_distribution)
+    res = []
+    for i in range(lo, hi):
+        RecordingPQ.log = []
+        with torch.no_grad():
+            loc, tim = searcher.astar_search(model, [int(od['start'][i])], [int(od['start_time'][i])],
+                                             int(od['des'][i]), int(od['default_len'][i]), max_step=5000)
+        pops = nonstale(RecordingPQ.log)
+        res.append((i, [int(x) for x in loc], [int(x) for x in tim], [p[0] for p in pops], [p[1] for p in pops]))
+    probe = {k: float(v.detach().double().sum()) for k, v in model.state_dict().items()
+             if k in ('function_g.lstm.weight_ih_l0', 'function_g.out_fc.weight',
+                      'function_h.gat_encoder.linear_proj.weight', 'function_h.emb_fc.weight')}
+    return res, probe
+
+
+def gen_bj_dims_config0(workers=6):
+    """BASELINE.json configs[0] as written, run by the REFERENCE: 32 x 32 street grid (N = 1 984), BJ model dims,
+    reference constructors under torch.manual_seed(0), 256 OD pairs (RandomState(2)), max_step 5000.  Stores the
+    trajectories and the pop traces (rid int16 / priority f32); no weights (41 MB): the mirrors reproduce the
+    init from the same seed, and `weight_sums` lets the test check that they did."""
+    import multiprocessing as mp
+    chunks = [(i, min(256, i + 4)) for i in range(0, 256, 4)]
+    with mp.get_context('fork').Pool(workers) as pool:
+        parts = pool.map(_bj_worker, chunks, chunksize=1)
+    rows = sorted([r for part, _ in parts for r in part])
+    probe = parts[0][1]
+    lens = np.array([len(r[1]) for r in rows], dtype=np.int32)
+    npop = np.array([len(r[3]) for r in rows], dtype=np.int32)
+    out = {'len': lens, 'loc': np.concatenate([np.asarray(r[1], dtype=np.int32) for r in rows]),
+           'tim': np.concatenate([np.asarray(r[2], dtype=np.int32) for r in rows]),
+           'npop': npop, 'pop_rid': np.concatenate([np.asarray(r[3], dtype=np.int16) for r in rows]),
+           'pop_prio': np.concatenate([np.asarray(r[4], dtype=np.float32) for r in rows]),
+           'weight_sum_names': np.array(sorted(probe.keys())),
+           'weight_sums': np.array([probe[k] for k in sorted(probe.keys())], dtype=np.float64)}
+    np.savez_compressed(os.path.join(OUT, 'g11_bj_dims_config0.npz'), **out)
+    print('G11 done: 256 OD pairs, mean length %.1f, mean pops %.0f' % (lens.mean(), npop.mean()))
+
+
+
 if __name__ == '__main__':
     only = sys.argv[1] if len(sys.argv) > 1 else 'all'
+    if only == 'g10':                     # adds G10 next to the existing files (same deterministic world)
+        net = messy_network()
+        gen_masked_batch(net, build_road_model(net))
+        sys.exit(0)
+    if only == 'g11':                     # ~20 minutes on 8 cores: the reference itself at BJ dims
+        gen_bj_dims_config0()
+        sys.exit(0)
     if only == 'g9':                      # adds G9 next to the existing files (same deterministic world)
         net = messy_network()
         gen_beam_search(net, build_road_model(net))
@@ -486,5 +600,7 @@ if __name__ == '__main__':
         gen_double_layer(net, model, rt)
         gen_random_sample(net, model, rt)
         gen_beam_search(net, model)
+        gen_masked_batch(net, model)
+        gen_bj_dims_config0()
     for fn in sorted(os.listdir(OUT)):
         print(fn, os.path.getsize(os.path.join(OUT, fn)))

@@ -18,7 +18,7 @@ GAT_STATIC_SCRATCH_BYTES = 8 << 20     # TSG_GAT_STATIC_SCRATCH_BYTES
 EXPORTS = ('tsg_version', 'tsg_gemm_f32', 'tsg_gat_forward', 'tsg_gat_forward_static', 'tsg_gat_build_input', 'tsg_lstm_step_batched',
            'tsg_score_candidates', 'tsg_engine_reset', 'tsg_engine_run', 'tsg_engine_run_profiled', 'tsg_engine_graph_create', 'tsg_engine_graph_launch',
            'tsg_engine_graph_destroy', 'tsg_frontier_expand_select',
-           'tsg_score_frontier', 'tsg_rollout_run', 'tsg_reconstruct_paths', 'tsg_h_pair_scores')
+           'tsg_score_frontier', 'tsg_rollout_run', 'tsg_reconstruct_paths', 'tsg_h_pair_scores', 'tsg_geodesic_pairs')
 
 _p = C.c_void_p
 _i32 = C.c_int32
@@ -50,7 +50,8 @@ class LstmStep(C.Structure):
 
 class ScoreBatch(C.Structure):
     _fields_ = [('n_rows', _i32), ('chain_ptr', _p), ('chain', _p), ('h_top', _p), ('cand_ptr', _p),
-                ('cand', _p), ('dis', _p), ('des', _p), ('prob', _p), ('prob_g', _p), ('prob_h', _p)]
+                ('cand', _p), ('dis', _p), ('des', _p), ('prob', _p), ('prob_g', _p), ('prob_h', _p),
+                ('logit_g', _p), ('logit_h', _p)]
 
 
 class Graph(C.Structure):
@@ -126,6 +127,7 @@ def lib():
     L.tsg_score_frontier.argtypes = [C.POINTER(Model), C.POINTER(Graph), C.POINTER(Engine), _i32, _p]
     L.tsg_reconstruct_paths.argtypes = [C.POINTER(Engine), _i32, _p, _p, _p, _p, _i32, _p, _p, _p, _p]
     L.tsg_h_pair_scores.argtypes = [C.POINTER(Model), _i32, _p, _p, _p, _p, _p]
+    L.tsg_geodesic_pairs.argtypes = [_p, _i32, _i32, _p, _p, _p, _p]
     L.tsg_rollout_run.argtypes = [C.POINTER(Model), C.POINTER(Graph), C.POINTER(Rollout), _i32, _p]
     for name in EXPORTS:
         getattr(L, name).restype = C.c_int

@@ -39,7 +39,7 @@ __device__ __forceinline__ float tsg_wave_max(float v) {
 __device__ __forceinline__ float tsg_sigmoid(float x) { return __frcp_rn(1.0f + __expf(-x)); }
 __device__ __forceinline__ float tsg_tanh(float x) { return 1.0f - 2.0f * __frcp_rn(1.0f + __expf(2.0f * x)); }
 
-// slot-state word indices (engine.slot_state is [B][32] int32)
+// slot-state word indices (engine.slot_state is [B][SS_WORDS = 40] int32)
 enum {
   SS_PHASE = 0, SS_OD, SS_STEP, SS_HEAP_N, SS_NODE_N, SS_EXP_N, SS_GEN, SS_WOFF, SS_DES, SS_DEFLEN,
   SS_MAXSTEP, SS_ALLOW, SS_WARM_K, SS_PLEN, SS_CUR_EXP, SS_CUR_RID, SS_CUR_C, SS_CUR_DATE_TIME,

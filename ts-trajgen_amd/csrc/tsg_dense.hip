@@ -121,6 +121,7 @@ struct LstmArgs {
   const int32_t* pc;     // engine mode: tsg_engine.counters
   int slots;             // engine mode
   int lstm_blocks;       // workgroups of the recurrence proper; the launch may carry cand_dis_block workgroups behind them
+  long long state_rows;  // explicit index arrays: rows of h / c (0 = unchecked); indices outside are dropped
   const float* h_below;
   float* h;
   float* c;
@@ -170,6 +171,10 @@ __device__ __forceinline__ bool lstm_tile_rows(const LstmArgs& a, int rowtile, I
     if (m < n) {
       pv = a.prev_idx[m];
       ov = a.out_idx[m];
+      if (a.state_rows > 0) {  // tsg_lstm_step.state_rows: never touch a row outside the state arrays
+        if (pv >= a.state_rows) pv = -1;
+        if (ov >= a.state_rows) ov = -1;
+      }
       if (LAYER0) {
         rd = a.rid[m];
         tc = a.tcode[m];
@@ -626,8 +631,9 @@ static int check_model_dims(const tsg_model* m) {
 int tsg_launch_lstm_layer(const tsg_model* m, int layer, int max_rows, const int32_t* n_rows_dev, int n_rows_host,
                           const int64_t* prev_idx, const int64_t* out_idx, const int32_t* rid, const int32_t* tcode,
                           const tsg_engine* eng, const float* h_below, float* h, float* c,
-                          hipStream_t stream, int split, const EngineDev* tail) {
+                          hipStream_t stream, int split, const EngineDev* tail, long long state_rows) {
   LstmArgs a;
+  a.state_rows = state_rows;
   a.layer = layer;
   a.hp = m->hp;
   a.n_rows_host = n_rows_host;
@@ -681,5 +687,6 @@ extern "C" int tsg_lstm_step_batched(const tsg_model* m, const tsg_lstm_step* s,
   if (!s->prev_idx || !s->out_idx) return TSG_E_INVALID;
   if (s->layer == 0 && (!s->rid || !s->tcode)) return TSG_E_INVALID;
   return tsg_launch_lstm_layer(m, s->layer, s->n_rows_host, s->n_rows_dev, s->n_rows_host, s->prev_idx, s->out_idx,
-                               s->rid, s->tcode, nullptr, s->h_below, s->h, s->c, (hipStream_t)stream, 0, nullptr);
+                               s->rid, s->tcode, nullptr, s->h_below, s->h, s->c, (hipStream_t)stream, 0, nullptr,
+                               (long long)s->state_rows);
 }

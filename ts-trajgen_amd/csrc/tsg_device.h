@@ -193,7 +193,8 @@ __device__ __forceinline__ float tsg_mix_softmax(const tsg_model& m, float g_log
 // softmaxes through pg/ph.  `pooled` = attention-pooled hidden in the load_row lane map.
 template <int JT>
 __device__ __forceinline__ float score_row(const tsg_model& m, const float pooled[JT], int J, int lane, int ncand,
-                                           int my_cand, float my_dis, int des, float* pg, float* ph) {
+                                           int my_cand, float my_dis, int des, float* pg, float* ph,
+                                           float* lg = nullptr, float* lh = nullptr) {
   const int hp = m.hp;
   // G: gathered rows of out_fc (function_g_fc.py:184-186) -- only the ncand rows that are needed
   float g_logit = -INFINITY;
@@ -224,5 +225,7 @@ __device__ __forceinline__ float score_row(const tsg_model& m, const float poole
   const float f = tsg_mix_softmax(m, g_logit, h_logit, lane < ncand, &g, &h);
   if (pg) *pg = g;
   if (ph) *ph = h;
+  if (lg) *lg = g_logit;
+  if (lh) *lh = h_logit;
   return f;
 }

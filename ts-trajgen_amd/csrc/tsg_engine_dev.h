@@ -12,6 +12,14 @@ struct EngineDev {
   tsg_od_batch od;
 };
 
+// One LSTM layer step (tsg_dense.hip).  Rows come either from explicit index arrays (prev_idx / out_idx / rid /
+// tcode, checked against state_rows when it is > 0) or, with `eng`, from the engine's work list; `tail`: the
+// candidate-distance workgroups of the superstep ride behind the recurrence's own (layer 0, split form).
+int tsg_launch_lstm_layer(const tsg_model* m, int layer, int max_rows, const int32_t* n_rows_dev, int n_rows_host,
+                          const int64_t* prev_idx, const int64_t* out_idx, const int32_t* rid, const int32_t* tcode,
+                          const tsg_engine* eng, const float* h_below, float* h, float* c, hipStream_t stream, int split,
+                          const EngineDev* tail, long long state_rows = 0);
+
 // Candidate distances of the superstep: one LANE per (work item, successor) pair instead of one wave per
 // item, so the fp64 Vincenty iteration runs on full wavefronts.  Writes kilometres * 10 as f32
 // (search.py:355-356) into cand_lp[slot][c], where the scoring kernel picks it up and overwrites it with

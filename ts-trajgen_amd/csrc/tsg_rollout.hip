@@ -4,12 +4,7 @@
 // kernels of tsg_dense.hip -> step kernel (one wave64 per trajectory: stop tests, candidate scoring,
 // inverse-CDF draw, append).  The reference's multinomial(1) becomes an inverse-CDF draw from caller-supplied
 // uniforms so that a rollout is reproducible on any device.
-#include "tsg_device.h"
-
-int tsg_launch_lstm_layer(const tsg_model* m, int layer, int max_rows, const int32_t* n_rows_dev, int n_rows_host,
-                          const int64_t* prev_idx, const int64_t* out_idx, const int32_t* rid, const int32_t* tcode,
-                          const tsg_engine* eng, const float* h_below, float* h, float* c,
-                          hipStream_t stream, int split, const struct EngineDev* tail);
+#include "tsg_engine_dev.h"
 
 struct RolloutDev {
   tsg_rollout r;

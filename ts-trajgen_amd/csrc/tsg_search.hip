@@ -8,11 +8,6 @@
 #define TSG_ABLATE 0  // timing-only ablation builds (tools/build_variant.sh); 0 in the shipped library
 #endif
 
-int tsg_launch_lstm_layer(const tsg_model* m, int layer, int max_rows, const int32_t* n_rows_dev, int n_rows_host,
-                          const int64_t* prev_idx, const int64_t* out_idx, const int32_t* rid, const int32_t* tcode,
-                          const tsg_engine* eng, const float* h_below, float* h, float* c,
-                          hipStream_t stream, int split, const struct EngineDev* tail);
-
 // =====================================================================================
 // explicit-row scoring: GeneratorV4.predict (generator_v4.py:56-72) for (prefix, candidates, dis) rows
 // =====================================================================================
@@ -47,12 +42,14 @@ __global__ __launch_bounds__(256) void score_batch_kernel(tsg_model m, tsg_score
   for (int j = 0; j < JT; ++j) pooled[j] = acc.v[j] * inv;
   const int my_cand = lane < ncand ? sb.cand[k0 + lane] : 0;
   const float my_dis = lane < ncand ? sb.dis[k0 + lane] : 0.0f;
-  float pg, ph;
-  const float f = score_row<JT>(m, pooled, J, lane, ncand, my_cand, my_dis, sb.des[row], &pg, &ph);
+  float pg, ph, lg, lh;
+  const float f = score_row<JT>(m, pooled, J, lane, ncand, my_cand, my_dis, sb.des[row], &pg, &ph, &lg, &lh);
   if (lane < ncand) {
     sb.prob[k0 + lane] = f;
     if (sb.prob_g) sb.prob_g[k0 + lane] = pg;
     if (sb.prob_h) sb.prob_h[k0 + lane] = ph;
+    if (sb.logit_g) sb.logit_g[k0 + lane] = lg;
+    if (sb.logit_h) sb.logit_h[k0 + lane] = lh;
   }
 }
 
@@ -96,6 +93,31 @@ extern "C" int tsg_h_pair_scores(const tsg_model* m, int32_t n, const int32_t* f
   if (!from || !to || !dis || !out) return TSG_E_INVALID;
   hipLaunchKernelGGL(h_pair_scores_kernel, dim3(tsg_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, *m, n, from, to,
                      dis, out);
+  TSG_LAUNCH_CHECK();
+  return 0;
+}
+
+// The candidate distance on explicit pairs (search.py:355-356): the same device function the engine's
+// cand_dis_block calls, exposed so that it can be checked on its own.
+__global__ void geodesic_pairs_kernel(const double* __restrict__ geo, int n_rows, int n, const int32_t* __restrict__ a,
+                                      const int32_t* __restrict__ b, double* __restrict__ out_m) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int ia = a[i], ib = b[i];
+  if (ia < 0 || ia >= n_rows || ib < 0 || ib >= n_rows) {
+    out_m[i] = -1.0;  // index outside the table
+    return;
+  }
+  out_m[i] = tsg_dev_geodesic_m(geo + 4 * (size_t)ia, geo + 4 * (size_t)ib);
+}
+
+extern "C" int tsg_geodesic_pairs(const double* geo, int32_t n_rows, int32_t n, const int32_t* a, const int32_t* b,
+                                  double* out_m, void* stream) {
+  if (!geo || n_rows <= 0 || n < 0) return TSG_E_INVALID;
+  if (n == 0) return 0;
+  if (!a || !b || !out_m) return TSG_E_INVALID;
+  hipLaunchKernelGGL(geodesic_pairs_kernel, dim3(tsg_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, geo, n_rows, n, a,
+                     b, out_m);
   TSG_LAUNCH_CHECK();
   return 0;
 }
@@ -667,9 +689,15 @@ __global__ __launch_bounds__(256) void frontier_kernel(EngineDev D, int superste
       deflen = od.default_len[odi];
       max_step = od.max_step[odi];
       allow = od.allow_label ? od.allow_label[odi] : -1;
+      if (plen < 1 || max_step < 0 || plen - 1 + max_step > D.e.exp_cap) {
+        // the expansion records of this engine cannot hold the search the caller asked for: report it (CT_ERROR,
+        // the OD pair ends as OVERFLOW) instead of running a different, shorter search
+        step = 0;
+        err = 1;
+        break;
+      }
       const int start_time = od.prefix_time[poff + plen - 1];
       woff = start_time >= 1440 ? 1440 : 0;
-      if (plen - 1 + max_step > D.e.exp_cap) max_step = D.e.exp_cap - (plen - 1);  // never hit: host sizes exp_cap
       for (int k = 0; k + 1 < plen; ++k) {
         em[(size_t)k * EM_WORDS + EM_PARENT] = k - 1;
         em[(size_t)k * EM_WORDS + EM_RID] = od.prefix_rid[poff + k];

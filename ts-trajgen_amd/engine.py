@@ -149,8 +149,18 @@ class ModelTables(object):
         self.c_model = m
 
     @torch.no_grad()
-    def predict(self, trace_loc, trace_time, des, candidate_set, candidate_dis, trace_mask=None):
-        """GeneratorV4.predict for (B, L) prefixes and (B, C) candidates; returns (p, g, h), each (B, C)."""
+    def predict(self, trace_loc, trace_time, des, candidate_set, candidate_dis, trace_mask=None, logits=False):
+        """GeneratorV4.predict for (B, L) prefixes and (B, C) candidates; returns (p, g, h), each (B, C); with
+        `logits` also function G's and function H's candidate scores before their softmax.
+
+        With `trace_mask` (1 = real, 0 = padding; function_g_fc.py:162-180) the recurrence runs over each row's
+        real positions only and the query is the last real hidden state, as the reference's packed LSTM does.
+        The attention, however, runs over EVERY position of the re-padded LSTM output: the reference assigns its
+        masked_fill to `mask`, not to the weights (function_g_fc.py:33), so the padded positions (all-zero rows
+        out of pad_packed_sequence) keep logit 0 and their share exp(0 - max) of the softmax.  That is what is
+        reproduced here: a row of length n in a batch padded to T attends over its n states plus T - n zero rows.
+        As in the reference, the mask must be as wide as the longest row (pad_packed_sequence pads to the longest
+        row of the batch and masked_fill then needs equal shapes)."""
         L = _lib.lib()
         dev = self.device
         B, T = trace_loc.shape
@@ -159,6 +169,23 @@ class ModelTables(object):
             raise ValueError('at most %d candidates per row' % _lib.TSG_MAX_DEGREE)
         loc = trace_loc.to(dev).to(torch.int32).contiguous()
         tim = trace_time.to(dev).to(torch.int32).contiguous()
+        if trace_mask is not None:
+            mk = trace_mask.to(dev) != 0
+            lens = mk.sum(dim=1).to(torch.int64)
+            if int(lens.min()) < 1:
+                raise RuntimeError('every row of a masked batch needs at least one real position '
+                                   '(pack_padded_sequence, function_g_fc.py:165)')
+            if int(lens.max()) != T:
+                raise RuntimeError('trace_mask must be as wide as the longest row: the reference re-pads the LSTM '
+                                   'output to the longest row and masked_fill needs equal shapes '
+                                   '(function_g_fc.py:33,167)')
+            pos0 = torch.arange(T, device=dev).unsqueeze(0)
+            if not bool((mk == (pos0 < lens.unsqueeze(1))).all()):
+                raise ValueError('trace_mask must be 1 on a prefix of every row (right padding)')
+            loc = torch.where(mk, loc, torch.zeros_like(loc))        # padding ids are never run through the model
+            tim = torch.where(mk, tim, torch.zeros_like(tim))
+        else:
+            lens = torch.full((B,), T, dtype=torch.int64, device=dev)
         if int(loc.min()) < 0 or int(loc.max()) >= self.xproj.shape[0]:
             raise IndexError('road id outside the road embedding table')
         if int(tim.min()) < 0 or int(tim.max()) >= self.n_time:
@@ -170,18 +197,17 @@ class ModelTables(object):
         if int(d32.min()) < 0 or int(d32.max()) >= self.n_nodes_h:
             raise IndexError('destination id outside the node embedding table')
         dis = candidate_dis.to(dev).float().contiguous()
-        if trace_mask is not None:
-            lens = trace_mask.to(dev).sum(dim=1).to(torch.int64)
-        else:
-            lens = torch.full((B,), T, dtype=torch.int64, device=dev)
         hp, nl = self.hp, self.n_layers
-        hs = [torch.empty((B * T, hp), dtype=torch.float32, device=dev) for _ in range(nl)]
-        cs = [torch.empty((B * T, hp), dtype=torch.float32, device=dev) for _ in range(nl)]
+        # state rows b * T + t; one more all-zero row at the end stands for every padded position
+        hs = [torch.zeros((B * T + 1, hp), dtype=torch.float32, device=dev) for _ in range(nl)]
+        cs = [torch.zeros((B * T + 1, hp), dtype=torch.float32, device=dev) for _ in range(nl)]
+        zero_row = B * T
         base = torch.arange(B, dtype=torch.int64, device=dev) * T
         stream = _lib.current_stream()
         with torch.cuda.device(dev):
             for t in range(T):
-                out_idx = (base + t).contiguous()
+                live = lens > t                     # rows whose position t is real
+                out_idx = torch.where(live, base + t, torch.full_like(base, -1)).contiguous()
                 prev_idx = (base + t - 1).contiguous() if t > 0 else torch.full_like(base, -1)
                 rid_t = loc[:, t].contiguous()
                 tc_t = tim[:, t].contiguous()
@@ -192,26 +218,32 @@ class ModelTables(object):
                     s.rid, s.tcode = _lib.ptr(rid_t), _lib.ptr(tc_t)
                     s.h_below = _lib.ptr(hs[l - 1]) if l > 0 else None
                     s.h, s.c = _lib.ptr(hs[l]), _lib.ptr(cs[l])
-                    s.state_rows = B * T
+                    s.state_rows = B * T + 1
                     _lib.check(L.tsg_lstm_step_batched(C.byref(self.c_model), C.byref(s), stream),
                                'tsg_lstm_step_batched')
-            chain_ptr = torch.zeros(B + 1, dtype=torch.int32, device=dev)
-            chain_ptr[1:] = torch.cumsum(lens, 0).to(torch.int32)
+            # chain of row b: T - len zero rows (the padded positions), then its real states, the last one = query
             pos = torch.arange(T, dtype=torch.int64, device=dev).unsqueeze(0).expand(B, T)
-            keep = pos < lens.unsqueeze(1)
-            chain = (base.unsqueeze(1) + pos)[keep].contiguous()
+            pad = T - lens
+            real = pos >= pad.unsqueeze(1)
+            chain = torch.where(real, base.unsqueeze(1) + pos - pad.unsqueeze(1),
+                                torch.full_like(pos, zero_row)).reshape(-1).contiguous()
+            chain_ptr = (torch.arange(B + 1, dtype=torch.int32, device=dev) * T).contiguous()
             cand_ptr = (torch.arange(B + 1, dtype=torch.int32, device=dev) * Cn).contiguous()
             prob = torch.empty((B, Cn), dtype=torch.float32, device=dev)
             pg = torch.empty_like(prob)
             ph = torch.empty_like(prob)
+            lg = torch.empty_like(prob) if logits else None
+            lh = torch.empty_like(prob) if logits else None
             sb = _lib.ScoreBatch()
             sb.n_rows = B
             sb.chain_ptr, sb.chain, sb.h_top = _lib.ptr(chain_ptr), _lib.ptr(chain), _lib.ptr(hs[nl - 1])
             sb.cand_ptr, sb.cand, sb.dis, sb.des = _lib.ptr(cand_ptr), _lib.ptr(cand), _lib.ptr(dis), _lib.ptr(d32)
             sb.prob, sb.prob_g, sb.prob_h = _lib.ptr(prob), _lib.ptr(pg), _lib.ptr(ph)
+            sb.logit_g, sb.logit_h = _lib.ptr(lg), _lib.ptr(lh)
             _lib.check(L.tsg_score_candidates(C.byref(self.c_model), C.byref(sb), stream), 'tsg_score_candidates')
+        if logits:
+            return prob, pg, ph, lg, lh
         return prob, pg, ph
-
 
     @torch.no_grad()
     def h_pair_scores(self, from_node, to_node, distance):

@@ -3,7 +3,8 @@
 Holds the reference's parameters under the reference's names (`road_emb`, `time_emb`, `lstm`,
 `intra_attn.w1/w2/w3` -- unused by the reference too, function_g_fc.py:17-19 -- and `out_fc`).  The
 arithmetic (incremental LSTM cell on MFMA, attention over the prefix, gathered out_fc rows) lives in
-libtsg.so and is driven by GeneratorV4 / the engine, which need G and H together."""
+libtsg.so and is driven by GeneratorV4 / the engine, which need G and H together; `forward` / `predict` /
+`predict_g` (function_g_fc.py:138-221) return G's share of that evaluation."""
 import torch.nn as nn
 
 
@@ -45,6 +46,22 @@ class FunctionGFC(nn.Module):
                                'construct the module as GeneratorV4(config, data_feature).function_g')
         return owner.predict_parts(trace_loc, trace_time, des, candidate_set, candidate_dis, trace_mask)[1]
 
-    def forward(self, *args, **kwargs):
-        raise NotImplementedError('use GeneratorV4.predict / the batched engine; function G alone has no '
-                                  'caller on the generation path')
+    def forward(self, trace_loc, trace_time, des, candidate_set, candidate_dis, trace_mask=None, train=True):
+        """The candidates' scores before the softmax: out_fc(attention-pooled LSTM state)[candidate_set]
+        (function_g_fc.py:138-187), for a module in inference mode (the dropouts of :160,182 are then the
+        identity; `train` is unused by the reference too).  Computed by the scoring kernel, which gathers only
+        the candidates' rows of out_fc."""
+        if self.training:
+            raise NotImplementedError('FunctionGFC.forward with live dropout (training) is outside the generation '
+                                      'path: call .train(False) first (our_model_generate.py:399)')
+        from .generator_v4 import owner_of
+        owner = owner_of(self, 'function_g')
+        if owner is None:
+            raise RuntimeError('FunctionGFC.forward runs through the device tables of its GeneratorV4: '
+                               'construct the module as GeneratorV4(config, data_feature).function_g')
+        return owner.predict_parts(trace_loc, trace_time, des, candidate_set, candidate_dis, trace_mask,
+                                   logits=True)[3]
+
+    def predict(self, trace_loc, trace_time, des, candidate_set, candidate_dis, trace_mask=None):
+        """softmax of forward() over the candidates (function_g_fc.py:189-204)."""
+        return self.predict_g(trace_loc, trace_time, des, candidate_set, candidate_dis, trace_mask)

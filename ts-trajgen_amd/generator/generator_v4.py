@@ -57,9 +57,10 @@ class GeneratorV4(nn.Module):
         return self._tables
 
     # -- reference API ---------------------------------------------------------------------------
-    def predict_parts(self, trace_loc, trace_time, des, candidate_set, candidate_dis, trace_mask=None):
-        """(p, g, h): the mixed probability and the two inner softmaxes (predict_g / predict_next)."""
-        return self.tables().predict(trace_loc, trace_time, des, candidate_set, candidate_dis, trace_mask)
+    def predict_parts(self, trace_loc, trace_time, des, candidate_set, candidate_dis, trace_mask=None, logits=False):
+        """(p, g, h): the mixed probability and the two inner softmaxes (predict_g / predict_next); with `logits`
+        also the candidate scores of G and H before their softmax (FunctionGFC.forward / DistanceGatFC.forward)."""
+        return self.tables().predict(trace_loc, trace_time, des, candidate_set, candidate_dis, trace_mask, logits)
 
     def predict(self, trace_loc, trace_time, des, candidate_set, candidate_dis, trace_mask=None, cache=True):
         if not cache:
@@ -70,6 +71,6 @@ class GeneratorV4(nn.Module):
         """(1-w1)*g + w1*h before the outer softmax (generator_v4.py:54)."""
         if not cache:
             raise NotImplementedError()
-        _, g, h = self.predict_parts(trace_loc, trace_time, des, candidate_set, candidate_dis, trace_mask)
+        _, g, h = self.predict_parts(trace_loc, trace_time, des, candidate_set, candidate_dis, trace_mask)[:3]
         w1 = self.w1.detach()
         return torch.add((1 - w1) * g, w1 * h)

@@ -266,6 +266,8 @@ class DoubleLayerSearcher(object):
     # -- region stage ----------------------------------------------------------------------------
     def _region_paths(self, region_model, start_regions, start_times, des_regions, max_step):
         n = len(des_regions)
+        if n == 0:
+            return [], []
         res = self._regions().generate(region_model, start_regions, start_times, des_regions,
                                        np.full(n, 10, dtype=np.int32),      # best_default_len = 10 (search.py:967)
                                        max_step=max_step,
@@ -304,9 +306,14 @@ class DoubleLayerSearcher(object):
     # -- batched two-stage generation ------------------------------------------------------------
     @torch.no_grad()
     def generate(self, region_model, road_model, start_rids, start_times, des_rids, default_lens, max_step=500,
-                 seeds=None, rngs=None, slots=None):
-        """Returns (list of trace_loc, list of trace_tim, list of is_astar)."""
+                 seeds=None, rngs=None, slots=None, leg_lmax=None):
+        """Returns (list of trace_loc, list of trace_tim, list of is_astar).
+        leg_lmax: width of the output rows of a round of legs (default: 256 or more, by the longest prefix); legs
+        whose trajectory is longer are run again with a wider row, so the value never changes a result."""
         n = len(des_rids)
+        if n == 0:          # e.g. a rank whose shard of the OD list is empty: nothing to run, still a valid result
+            self.last_stats = {'rounds': 0, 'road_expansions': 0}
+            return [], [], []
         ms = np.broadcast_to(np.asarray(max_step, dtype=np.int32), (n,)).copy()
         if rngs is None:
             rngs = [None] * n      # RandomState(seed of OD i), made when OD i first draws (seeding costs 25 us)
@@ -375,7 +382,7 @@ class DoubleLayerSearcher(object):
             np.cumsum(ln, out=ptr[1:])
             keep = np.arange(cap)[None, :] < ln[:, None]
             lmax = max(256, int(ln.max()) + 64, int(dl_np[act].max()) + 1)
-            lmax = (lmax + 255) // 256 * 256
+            lmax = (lmax + 255) // 256 * 256 if leg_lmax is None else int(leg_lmax)
             tgt = target[act]
             res = self.road_search.generate(road_model, None, None, tgt, dl_np[act], max_step=ms[act],
                                             prefixes=(ptr, p_rid[act][keep], p_tim[act][keep]), allow_label=allow[act],
@@ -384,8 +391,32 @@ class DoubleLayerSearcher(object):
             rounds += 1
             r_rid, r_time = res['rid'].numpy(), res['time'].numpy()
             r_len, r_status = res['len'].numpy().astype(np.int64), res['status'].numpy()
-            if ((r_status & _lib.STATUS_OVERFLOW) != 0).any() or int(r_len.max()) > r_rid.shape[1]:
-                raise RuntimeError('trajectory longer than the output row')
+            over = ((r_status & _lib.STATUS_OVERFLOW) != 0) | (r_len > r_rid.shape[1])
+            if over.any():
+                # a leg longer than the output row (the reference has no length limit): run those legs again with a
+                # row wide enough for the longest of them, as Searcher._single does; the other legs keep their result
+                oi = np.flatnonzero(over)
+                if (r_len[oi] <= 0).any():
+                    raise RuntimeError('A* engine hit a workspace cap (node/heap/exp capacity)')
+                wide = (int(r_len[oi].max()) + 255) // 256 * 256
+                optr = np.zeros(len(oi) + 1, dtype=np.int32)
+                np.cumsum(ln[oi], out=optr[1:])
+                res2 = self.road_search.generate(road_model, None, None, tgt[oi], dl_np[act][oi], max_step=ms[act][oi],
+                                                 prefixes=(optr, p_rid[act][oi][keep[oi]], p_tim[act][oi][keep[oi]]),
+                                                 allow_label=allow[act][oi], slots=slots, lmax=wide)
+                st2 = res2['status'].numpy()
+                if ((st2 & _lib.STATUS_OVERFLOW) != 0).any():
+                    raise RuntimeError('trajectory longer than the widened output row')
+                grown_r = np.zeros((m, wide), dtype=np.int32)
+                grown_t = np.zeros((m, wide), dtype=np.int32)
+                grown_r[:, :r_rid.shape[1]] = r_rid
+                grown_t[:, :r_rid.shape[1]] = r_time
+                grown_r[oi] = res2['rid'].numpy()
+                grown_t[oi] = res2['time'].numpy()
+                r_rid, r_time = grown_r, grown_t
+                r_len[oi] = res2['len'].numpy().astype(np.int64)
+                r_status = r_status.copy()
+                r_status[oi] = st2
             if r_rid.shape[1] > cap:
                 grow = r_rid.shape[1] - cap
                 p_rid = np.concatenate([p_rid, np.zeros((n, grow), dtype=np.int32)], axis=1)
