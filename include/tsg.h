@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define TSG_ABI_VERSION 1
+#define TSG_ABI_VERSION 2
 
 #define TSG_E_INVALID (-1)   /* bad dims / null pointer / misaligned */
 #define TSG_E_TOO_SMALL (-2) /* a caller-provided buffer is smaller than required */
@@ -260,9 +260,13 @@ typedef struct tsg_engine {
   /* workspaces (caller-allocated); *_bytes are checked against the dims above */
   int32_t* slot_state;  size_t slot_state_bytes;  /* [B][40] int32 */
   uint64_t* heap;       size_t heap_bytes;        /* [B][heap_cap] {float prio; int32 node} */
-  uint32_t* table;      size_t table_bytes;       /* [B][n_roads] rid -> (generation << 20 | node index); generation 0 =
-                                                     never seen, so tsg_engine_reset zeroes it once per OD batch */
-  int32_t* nodes;       size_t nodes_bytes;       /* [B][node_cap][8] int32 */
+  uint64_t* table;      size_t table_bytes;       /* [B][n_roads] rid -> low word: generation << 20 | node index (generation
+                                                     0 = never seen, so tsg_engine_reset zeroes it once per OD batch); high
+                                                     word: the node's current log_prob as f32 while it is open (rid2node),
+                                                     +inf once it is closed (close_set), so relaxation and the
+                                                     futile-expansion check need no node record */
+  int32_t* nodes;       size_t nodes_bytes;       /* [B][node_cap][8] int32 {rid, parent, log_prob, date_time, state,
+                                                     indptr[rid], out-degree, depth} */
   int32_t* exp_meta;    size_t exp_meta_bytes;    /* [B][exp_cap][4] {parent, rid, tcode, depth} */
   int32_t* exp_up;      size_t exp_up_bytes;      /* [n_pages*64][64]: exp_up[row][i] = state row of the (i+1)-th ancestor
                                                      of the node in state row `row`, -1 = none */
@@ -306,6 +310,11 @@ typedef struct tsg_engine {
   int32_t* item_counts; size_t item_counts_bytes; /* [2][R][32]: n_long, n_short of each stretch (one 128-byte line each),
                                                      one plane per superstep parity */
   float* cand_lp;       size_t cand_lp_bytes;     /* [B][max_degree] */
+  int32_t* cand_id;     size_t cand_id_bytes;     /* [B][max_degree] successors of the expansion the search waits for (left by
+                                                     the frontier kernel for the distance and scoring kernels and for its own
+                                                     relaxation in the next superstep) */
+  int32_t* row_meta;    size_t row_meta_bytes;    /* [n_pages*64][2] {rid, time code} of every state row: with exp_up, a finished
+                                                     search's trajectory is written 64 points per read */
   int32_t* shared_counters;                       /* [16] words 2,3,4,6 below; == counters for a lone engine.  Several
                                                      engines (disjoint workspaces, one HIP stream each) that work on
                                                      the SAME tsg_od_batch share this array: one OD queue */

@@ -30,7 +30,7 @@ def region():
 
 def test_library_loads():
     from ts_trajgen_amd import _lib
-    assert _lib.lib().tsg_version() == 1
+    assert _lib.lib().tsg_version() == 2
 
 
 @pytest.mark.parametrize('m,n,k', [(1, 1, 1), (130, 70, 33), (257, 1280, 30), (512, 256, 256), (1000, 40, 512)])

@@ -37,7 +37,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), name
     from ts_trajgen_amd import _lib
     assert set(_lib.EXPORTS) == declared
-    assert lib.tsg_version() == 1
+    assert lib.tsg_version() == 2
 
 
 def test_struct_sizes_match_header(tmp_path):

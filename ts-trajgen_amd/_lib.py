@@ -77,6 +77,7 @@ class Engine(C.Structure):
                 ('slot_pages', _p), ('slot_pages_bytes', _sz), ('page_ring', _p), ('page_ring_bytes', _sz),
                 ('retry', _p), ('retry_bytes', _sz), ('page_flags', _p), ('page_flags_bytes', _sz),
                 ('items', _p), ('items_bytes', _sz), ('item_counts', _p), ('item_counts_bytes', _sz), ('cand_lp', _p), ('cand_lp_bytes', _sz),
+                ('cand_id', _p), ('cand_id_bytes', _sz), ('row_meta', _p), ('row_meta_bytes', _sz),
                 ('shared_counters', _p), ('counters', _p), ('counters_bytes', _sz)]
 
 

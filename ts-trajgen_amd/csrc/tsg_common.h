@@ -45,6 +45,7 @@ enum {
   SS_MAXSTEP, SS_ALLOW, SS_WARM_K, SS_PLEN, SS_CUR_EXP, SS_CUR_RID, SS_CUR_C, SS_CUR_DATE_TIME,
   SS_CUR_LP, SS_BEST_LP, SS_BEST_PARENT, SS_BEST_RID, SS_BEST_TCODE, SS_HAVE_BEST, SS_NPOP, SS_POFF,
   SS_CUR_DEPTH, SS_ST_EVALS, SS_ST_CAND, SS_ST_CHAIN, SS_CUR_COST, SS_ST_SKIPPED, SS_ST_ITEMS, SS_PAGES, SS_ST_STALLS,
+  SS_LAST_PAGE,  // the state page taken last (= the page of the next expansion's row once ensure_page succeeded)
   SS_WORDS = 40
 };
 enum { PH_IDLE = 0, PH_WARMUP = 1, PH_SEARCH = 2, PH_EXPANDED = 3, PH_DONE = 4 };
@@ -100,8 +101,9 @@ __device__ __forceinline__ void tsg_item_counts(const int32_t* counts, const int
 __host__ __device__ inline bool tsg_item_filled(int p, int rs, int n_long, int n_short) {
   return p < n_long || (p >= rs - n_short && p < rs);
 }
-// node record words ([B][node_cap][8] int32)
-enum { ND_RID = 0, ND_PARENT, ND_LP, ND_DATE_TIME, ND_EXP, ND_WORDS = 8 };
+// node record words ([B][node_cap][8] int32): BEG / C = CSR row of the node's road (indptr[rid], out-degree), DEPTH =
+// length of the trajectory that ends in the node (its current parent's depth + 1)
+enum { ND_RID = 0, ND_PARENT, ND_LP, ND_DATE_TIME, ND_EXP, ND_BEG, ND_C, ND_DEPTH, ND_WORDS = 8 };
 enum { ND_OPEN = -1, ND_CLOSED_NOSLOT = -2 };
 // expanded-slot meta words ([B][exp_cap][4] int32)
 enum { EM_PARENT = 0, EM_RID, EM_TCODE, EM_DEPTH, EM_WORDS = 4 };

@@ -108,7 +108,7 @@ __device__ __forceinline__ void cand_dis_block(const EngineDev& D, int block) {
   int n_long, n_short;
   tsg_item_counts(D.e.item_counts, D.e.counters, D.e.slots, region, n_long, n_short);
   if (!tsg_item_filled(pos, tsg_region_size(D.e.slots, region), n_long, n_short) || ncand < 2 || c >= ncand) return;
-  const int cand = D.g.indices[D.g.indptr[it[IT_RID]] + c];
+  const int cand = D.e.cand_id[(size_t)it[IT_SLOT] * md + c];  // the successor list the frontier kernel left
   float dis;
   if (D.g.dist_table) {  // region graphs: region_dist[c][des] / 100 (search.py:1049)
     dis = (float)(D.g.dist_table[(size_t)cand * D.g.n_roads + it[IT_DES]] / 100.0);

@@ -128,9 +128,6 @@ extern "C" int tsg_geodesic_pairs(const double* geo, int32_t n_rows, int32_t n, 
 #ifndef TSG_SCORE_WPB
 #define TSG_SCORE_WPB 1
 #endif
-#ifndef TSG_FRONTIER_WPB
-#define TSG_FRONTIER_WPB 4
-#endif
 
 // =====================================================================================
 // engine scoring: one wave per work item of the current superstep
@@ -179,7 +176,7 @@ __global__ __launch_bounds__(256) void score_frontier_kernel(tsg_model m, Engine
   // lane i: the state row of the (i+1)-th ancestor; kept in a register (this wave must not read back its own store)
   int mine = lane == 0 ? parent : (parent >= 0 ? anc[(size_t)parent * LV + lane - 1] : -1);
   anc[(size_t)e * LV + lane] = mine;
-  const int rid = it[IT_RID], des = it[IT_DES];
+  const int des = it[IT_DES];
   if (ncand < 2) return;  // warm-up rows and single-successor expansions need no model call (search.py:302)
   const float lp_parent = __int_as_float(it[IT_LP]);
   const int hp = m.hp, J = hp / 64;
@@ -237,8 +234,8 @@ __global__ __launch_bounds__(256) void score_frontier_kernel(tsg_model m, Engine
   int my_cand = 0;
   float my_dis = 0.0f;
   if (lane < ncand) {
-    my_cand = D.g.indices[D.g.indptr[rid] + lane];
-    my_dis = D.e.cand_lp[(size_t)b * D.g.max_degree + lane];  // written by cand_dis_kernel
+    my_cand = D.e.cand_id[(size_t)b * D.g.max_degree + lane];  // the successor list the frontier kernel left
+    my_dis = D.e.cand_lp[(size_t)b * D.g.max_degree + lane];   // written by cand_dis_kernel
   }
 #if TSG_ABLATE == 3
   const float f = 1.0f / ncand + pooled[0] * 1e-9f + my_dis * 1e-9f;
@@ -277,35 +274,22 @@ static void launch_score_frontier(const tsg_model* m, const EngineDev& D, int su
 // =====================================================================================
 // frontier kernel: one thread per in-flight search
 // =====================================================================================
+// The work of a search in a superstep is a chain of dependent small accesses; what it costs is the number of
+// round trips to memory on that chain.  The data structures are laid out so that a look-up is one round trip:
+//   * the rid table carries the open node's log_prob next to the node index (+inf once the road is closed), so
+//     relaxation and the futile-expansion check never read a node record;
+//   * a node record carries the CSR row of its road and its depth, so a popped node needs no indptr / parent read;
+//   * the slot keeps the successor list of the expansion it waits for (cand_id, also read by the distance and
+//     scoring kernels) and the page of its next state row;
+//   * _siftdown after a pop starts from entries the sift just read;
+//   * a finished search writes its trajectory from the ancestor lists (exp_up) and row_meta, eight points per
+//     two round trips, instead of walking the parent chain one point at a time.
+// (One WAVE per search cuts the round trips further, to 10-14 per superstep, but 24 576 waves of ~1 900
+// instructions are issue-bound: 90 us per launch against this kernel's time; ablate/frontier_wave_per_search.hip.txt.)
 struct HeapEnt {
   float prio;
   int node;
 };
-
-#ifndef TSG_STAMP
-#define TSG_STAMP 0  // diagnostic build only: cycle shares of the frontier kernel's phases (never shipped)
-#endif
-#if TSG_STAMP
-__device__ unsigned long long g_stamp[16];
-#define CKPT(i)                         \
-  {                                     \
-    const long long _n = clock64();     \
-    st_acc[i] += _n - st_last;          \
-    st_last = _n;                       \
-  }
-#define STAMP_ADD(i, v) st_acc[i] += (long long)(v)
-extern "C" int tsg_debug_read_stamps(unsigned long long* out_host, int reset) {
-  if (hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_stamp), sizeof(g_stamp)) != hipSuccess) return -1;
-  if (reset) {
-    unsigned long long z[16] = {0};
-    if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamp), z, sizeof(z)) != hipSuccess) return -1;
-  }
-  return 0;
-}
-#else
-#define CKPT(i)
-#define STAMP_ADD(i, v)
-#endif
 
 __device__ __forceinline__ HeapEnt heap_ld(const uint64_t* h, int i) {
   const uint64_t v = h[i];
@@ -363,7 +347,8 @@ __device__ __forceinline__ void heap_push(uint64_t* h, int& n, HeapEnt item, con
 }
 // heapq.heappop == pop last, put it at the root, _siftup (bubble the smaller child up to a leaf, then
 // _siftdown).  Three levels below the current position (2 + 4 + 8 entries, contiguous per level) are
-// fetched per round trip; the decisions are the same comparisons in the same order.
+// fetched per round trip; the decisions are the same comparisons in the same order.  _siftdown's first
+// comparison is against the entry the sift moved last, which is still in a register.
 __device__ __forceinline__ HeapEnt heap_pop(uint64_t* h, int& n, const int32_t* nodes) {
   const HeapEnt last = heap_ld(h, n - 1);
   --n;
@@ -371,6 +356,7 @@ __device__ __forceinline__ HeapEnt heap_pop(uint64_t* h, int& n, const int32_t* 
   const HeapEnt ret = heap_ld(h, 0);
   const int hi = n - 1;
   int pos = 0;
+  uint64_t moved = 0;  // the entry that went from `pos` to its parent in the latest step
   while (2 * pos + 1 < n) {
     const int c0 = 2 * pos + 1, g0 = 4 * pos + 3, q0 = 8 * pos + 7;
     uint64_t cv[2], gv[4], qv[8];
@@ -383,7 +369,8 @@ __device__ __forceinline__ HeapEnt heap_pop(uint64_t* h, int& n, const int32_t* 
     // level 1
     int s1 = 0;
     if (c0 + 1 < n && !ent_less(ent_of(cv[0]), ent_of(cv[1]), nodes)) s1 = 1;
-    h[pos] = cv[s1];
+    moved = cv[s1];
+    h[pos] = moved;
     pos = c0 + s1;
     int child = 2 * pos + 1;
     if (child >= n) break;
@@ -391,7 +378,8 @@ __device__ __forceinline__ HeapEnt heap_pop(uint64_t* h, int& n, const int32_t* 
     const uint64_t gl = s1 ? gv[2] : gv[0], gr = s1 ? gv[3] : gv[1];
     int s2 = 0;
     if (child + 1 < n && !ent_less(ent_of(gl), ent_of(gr), nodes)) s2 = 1;
-    h[pos] = s2 ? gr : gl;
+    moved = s2 ? gr : gl;
+    h[pos] = moved;
     pos = child + s2;
     child = 2 * pos + 1;
     if (child >= n) break;
@@ -401,15 +389,24 @@ __device__ __forceinline__ HeapEnt heap_pop(uint64_t* h, int& n, const int32_t* 
     const uint64_t qr = sel == 0 ? qv[1] : sel == 1 ? qv[3] : sel == 2 ? qv[5] : qv[7];
     int s3 = 0;
     if (child + 1 < n && !ent_less(ent_of(ql), ent_of(qr), nodes)) s3 = 1;
-    h[pos] = s3 ? qr : ql;
+    moved = s3 ? qr : ql;
+    h[pos] = moved;
     pos = child + s3;
   }
-  while (pos > 0) {
-    const int pp = (pos - 1) >> 1;
-    const HeapEnt par = heap_ld(h, pp);
-    if (!ent_less(last, par, nodes)) break;
-    heap_st(h, pos, par);
-    pos = pp;
+  // _siftdown(heap, 0, pos): the parent of `pos` now holds `moved`
+  if (pos > 0) {
+    if (ent_less(last, ent_of(moved), nodes)) {
+      int pp = (pos - 1) >> 1;
+      heap_st(h, pos, ent_of(moved));
+      pos = pp;
+      while (pos > 0) {
+        pp = (pos - 1) >> 1;
+        const HeapEnt par = heap_ld(h, pp);
+        if (!ent_less(last, par, nodes)) break;
+        heap_st(h, pos, par);
+        pos = pp;
+      }
+    }
   }
   heap_st(h, pos, last);
   return ret;
@@ -460,50 +457,115 @@ __global__ void reconstruct_paths_kernel(tsg_engine e, int n, const int32_t* slo
   out_len[i] = depth;
 }
 
+// The same trajectory from the ancestor lists: exp_up[row] names the 64 nearest ancestors' state rows of the
+// node in `row`, row_meta[row] = (rid, time code).  Eight points per two round trips (a list read, then the rows).
+__device__ __forceinline__ void write_path_rows(const tsg_engine& e, int parent_row, int rid, int tcode, int depth,
+                                                int32_t* orid, int32_t* otim, int lmax) {
+  if (depth - 1 < lmax) {
+    orid[depth - 1] = rid;
+    otim[depth - 1] = tcode;
+  }
+  int anchor = parent_row;  // sits at position `top`
+  int top = depth - 2;
+  while (anchor >= 0 && top >= 0) {
+    {
+      const int2 rm = *reinterpret_cast<const int2*>(e.row_meta + 2 * (size_t)anchor);
+      if (top < lmax) {
+        orid[top] = rm.x;
+        otim[top] = rm.y;
+      }
+    }
+    const int32_t* up = e.exp_up + (size_t)anchor * TSG_UP_LEVELS;
+    int next_anchor = -1;
+    for (int i0 = 0; i0 < TSG_UP_LEVELS && top - 1 - i0 >= 0; i0 += 8) {
+      int4 a[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) a[u] = *reinterpret_cast<const int4*>(up + i0 + 4 * u);
+      const int rows[8] = {a[0].x, a[0].y, a[0].z, a[0].w, a[1].x, a[1].y, a[1].z, a[1].w};
+      int2 rm[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int r = rows[u];
+        rm[u] = *reinterpret_cast<const int2*>(e.row_meta + 2 * (size_t)(r >= 0 ? r : 0));
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int pos = top - 1 - i0 - u;
+        if (rows[u] >= 0 && pos >= 0 && pos < lmax) {
+          orid[pos] = rm[u].x;
+          otim[pos] = rm[u].y;
+        }
+      }
+      if (i0 + 8 == TSG_UP_LEVELS) next_anchor = rows[7];
+    }
+    // the list's last entry is the anchor's 64th ancestor: it sits at position top - 64
+    anchor = next_anchor;
+    top -= TSG_UP_LEVELS;
+  }
+}
+
 // TSG_SPW searches per wave (one lane each, the other lanes idle): the work is a chain of dependent small
 // accesses, so what matters is how many chains are in flight and how long a search waits for the slowest
 // search of its wave (every divergent loop runs to the longest trip count in the wave), not lane use.
-// 8: with 24 576 searches in flight, 4 per wave are 6 144 waves = two rounds at this kernel's register count
-// (106 us per launch); 8 or 16 per wave fit in one round (91 us).
 #ifndef TSG_SPW
 #define TSG_SPW 8
+#endif
+#ifndef TSG_FRONTIER_WPB
+#define TSG_FRONTIER_WPB 4
 #endif
 static_assert(TSG_REGION_SLOTS % TSG_SPW == 0, "the searches of a wave share one region of the work list");
 __global__ __launch_bounds__(256) void frontier_kernel(EngineDev D, int superstep) {
   const int b = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * TSG_SPW + (threadIdx.x & 63);
   if (b >= D.e.slots || (threadIdx.x & 63) >= TSG_SPW) return;
-  // the plane of item_counts this launch fills (superstep parity), for the kernels that follow; nothing reads
-  // the word during this launch
-  if (b == 0) D.e.counters[PC_ITEM_PLANE] = D.e.counters[PC_SUPERSTEP] & 1;
-  int32_t* S = D.e.slot_state + (size_t)b * SS_WORDS;
-  int phase = S[SS_PHASE];
-  if (phase == PH_DONE) return;
   const tsg_graph& g = D.g;
   const tsg_od_batch& od = D.od;
+  const int md = g.max_degree;
+  int32_t* S = D.e.slot_state + (size_t)b * SS_WORDS;
+  int32_t* pc = D.e.counters;
+  // ---- first round trip: the slot state, the control words and (whether or not they are needed) the first
+  // successors and scored log-probs of the expansion this search may be waiting for
+  int4 sq[SS_WORDS / 4];
+#pragma unroll
+  for (int i = 0; i < SS_WORDS / 4; ++i) sq[i] = reinterpret_cast<const int4*>(S)[i];
+  const int ss_now = pc[PC_SUPERSTEP];
+  const int tail_snap = pc[PC_TAIL_SNAP], rtail_snap = pc[PC_RTAIL_SNAP];
+  const int abort_level = pc[PC_ABORT_LEVEL];
+  int cc0[4];
+  float lp0[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int i = k < md ? k : md - 1;
+    cc0[k] = D.e.cand_id[(size_t)b * md + i];
+    lp0[k] = D.e.cand_lp[(size_t)b * md + i];
+  }
+  // the plane of item_counts this launch fills (superstep parity), for the kernels that follow; nothing reads
+  // the word during this launch
+  if (b == 0) pc[PC_ITEM_PLANE] = ss_now & 1;
+  const int* sv = reinterpret_cast<const int*>(sq);
+  int phase = sv[SS_PHASE];
+  if (phase == PH_DONE) return;
   int32_t itw[IT_WORDS] = {0};  // the work item of this superstep, if one is emitted: written to the work list at the end
   int32_t* shared = D.e.shared_counters;  // OD queue + completion, common to all sub-engines of a batch
   uint64_t* heap = D.e.heap + (size_t)b * D.e.heap_cap;
-  uint32_t* table = D.e.table + (size_t)b * g.n_roads;
+  uint64_t* table = D.e.table + (size_t)b * g.n_roads;
   int32_t* nodes = D.e.nodes + (size_t)b * D.e.node_cap * ND_WORDS;
   int32_t* em = D.e.exp_meta + (size_t)b * D.e.exp_cap * EM_WORDS;
 
-  int odi = S[SS_OD], step = S[SS_STEP], heap_n = S[SS_HEAP_N], node_n = S[SS_NODE_N], exp_n = S[SS_EXP_N];
-  int gen = S[SS_GEN], woff = S[SS_WOFF], des = S[SS_DES], deflen = S[SS_DEFLEN], max_step = S[SS_MAXSTEP];
-  int allow = S[SS_ALLOW], warm_k = S[SS_WARM_K], plen = S[SS_PLEN], poff = S[SS_POFF];
-  float best_lp = __int_as_float(S[SS_BEST_LP]);
-  int best_parent = S[SS_BEST_PARENT], best_rid = S[SS_BEST_RID], best_tcode = S[SS_BEST_TCODE];
-  int have_best = S[SS_HAVE_BEST], npop = S[SS_NPOP];
-  // statistics: kept in registers for the launch (a read-modify-write on S[] is a dependent round trip each)
-  int st_evals = S[SS_ST_EVALS], st_cand = S[SS_ST_CAND], st_chain = S[SS_ST_CHAIN];
-  int st_skipped = S[SS_ST_SKIPPED], st_items = S[SS_ST_ITEMS], st_stalls = S[SS_ST_STALLS];
+  // The words every superstep works with live in registers and go back at the end; the others (prefix, fallback
+  // snapshot, the expansion waited for) are written where they change and read where they are needed, and the
+  // statistics are added with atomics nobody waits for: registers held across the whole kernel cost occupancy.
+  int odi = sv[SS_OD], step = sv[SS_STEP], heap_n = sv[SS_HEAP_N], node_n = sv[SS_NODE_N], exp_n = sv[SS_EXP_N];
+  int gen = sv[SS_GEN], woff = sv[SS_WOFF], des = sv[SS_DES], deflen = sv[SS_DEFLEN], max_step = sv[SS_MAXSTEP];
+  int allow = sv[SS_ALLOW], npop = sv[SS_NPOP];
+  const int cur_exp = sv[SS_CUR_EXP], cur_rid = sv[SS_CUR_RID], cur_c = sv[SS_CUR_C], cur_date_time = sv[SS_CUR_DATE_TIME];
+  const int cur_cost = sv[SS_CUR_COST], cur_lp = sv[SS_CUR_LP], cur_depth = sv[SS_CUR_DEPTH];
+  const float best_lp_in = __int_as_float(sv[SS_BEST_LP]);
+  int st_cand = 0, st_chain = 0, st_flags = 0;  // statistics of this superstep: bit 0 eval, 1 item, 2 stall, 8.. skipped
   int err = 0;
   // state pages (include/tsg.h, tsg_engine): this search's page list, the shared free ring, control words
-  int pages_held = S[SS_PAGES];
+  int pages_held = sv[SS_PAGES], last_page = sv[SS_LAST_PAGE];
   int32_t* my_pages = D.e.slot_pages + (size_t)b * D.e.pages_per_slot;
-  int32_t* pc = D.e.counters;
-  const int ss_stamp = pc[PC_SUPERSTEP] + 1;
-  const int tail_snap = pc[PC_TAIL_SNAP], rtail_snap = pc[PC_RTAIL_SNAP];
-  const int abort_level = pc[PC_ABORT_LEVEL];
+  const int ss_stamp = ss_now + 1;
   const bool active_at_entry = phase != PH_IDLE;
   const unsigned n_pages_u = (unsigned)D.e.n_pages;
   const unsigned retry_cap_u = (unsigned)(D.e.retry_bytes / 4);
@@ -513,7 +575,8 @@ __global__ __launch_bounds__(256) void frontier_kernel(EngineDev D, int superste
     if (pc[PC_HEAD] >= tail_snap) return false;  // cheap look before the atomic
     const int i = atomicAdd(&pc[PC_HEAD], 1);
     if (i >= tail_snap) return false;            // overshoot, clamped by the control step
-    my_pages[pages_held++] = D.e.page_ring[(unsigned)i % n_pages_u];
+    last_page = D.e.page_ring[(unsigned)i % n_pages_u];
+    my_pages[pages_held++] = last_page;
     return true;
   };
   auto release_pages = [&]() {
@@ -535,7 +598,7 @@ __global__ __launch_bounds__(256) void frontier_kernel(EngineDev D, int superste
   // a search that found no free page: wait, or (deadlock control) give the pages back and queue again
   auto stall = [&]() {
     D.e.page_flags[TSG_FLAG_PLANE + (b & 255) * 32] = ss_stamp;
-    ++st_stalls;
+    st_flags |= 4;
     if (abort_level > 0 && pages_held <= abort_level && active_at_entry && pc[PC_ABORT_BUDGET] > 0 &&
         atomicSub(&pc[PC_ABORT_BUDGET], pages_held + 1) > 0) {
       release_pages();
@@ -545,40 +608,41 @@ __global__ __launch_bounds__(256) void frontier_kernel(EngineDev D, int superste
       phase = PH_IDLE;
     }
   };
+  // close a node: it leaves rid2node for close_set (search.py:288-289); the rid table then answers +inf
+  auto close_node = [&](int node, int rid, int exp_word) {
+    nodes[(size_t)node * ND_WORDS + ND_EXP] = exp_word;
+    reinterpret_cast<uint32_t*>(table + rid)[1] = 0x7f800000u;
+  };
 
-#if TSG_STAMP
-  long long st_acc[16] = {0};
-  long long st_last = clock64();
-#endif
   // ---- relax the expansion scored during the previous superstep (search.py:385-419 / 317-350)
   if (phase == PH_EXPANDED) {
-    const int e = S[SS_CUR_EXP], C = S[SS_CUR_C], rid = S[SS_CUR_RID];
-    const int cur_date_time = S[SS_CUR_DATE_TIME], cur_cost = S[SS_CUR_COST];
-    const float lp_parent = __int_as_float(S[SS_CUR_LP]);
-    const int child_depth = S[SS_CUR_DEPTH] + 1;
-    const int base = g.indptr[rid];
+    const int e = cur_exp, C = cur_c, rid = cur_rid;
+    const float lp_parent = __int_as_float(cur_lp);
+    const int child_depth = cur_depth + 1;
+    float best_lp = best_lp_in;
     for (int i0 = 0; i0 < C && !err; i0 += 4) {
-      // the table entries and node records of up to four successors are fetched together; the pushes
-      // themselves stay in list order (search.py:385)
+      // the table entries (and CSR rows, for the nodes that turn out new) of up to four successors are fetched
+      // together; the pushes themselves stay in list order (search.py:385)
       int cc[4];
       float lps[4];
-      uint32_t tt[4];
-      int nexp[4];
-      float nlp[4];
+      uint64_t tt[4];
+      int cb[4], ce[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const int i = i0 + k < C ? i0 + k : C - 1;
-        cc[k] = g.indices[base + i];
-        lps[k] = (C == 1) ? lp_parent : D.e.cand_lp[(size_t)b * g.max_degree + i];
+        if (i0 == 0) {
+          cc[k] = cc0[k < C ? k : C - 1];
+          lps[k] = (C == 1) ? lp_parent : lp0[k < C ? k : C - 1];
+        } else {
+          cc[k] = D.e.cand_id[(size_t)b * md + i];
+          lps[k] = D.e.cand_lp[(size_t)b * md + i];
+        }
       }
 #pragma unroll
-      for (int k = 0; k < 4; ++k) tt[k] = table[cc[k]];
-#pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const bool seen = (int)(tt[k] >> TSG_GEN_SHIFT) == gen;
-        const int32_t* nd = nodes + (size_t)(seen ? (tt[k] & TSG_NODE_MASK) : 0) * ND_WORDS;
-        nexp[k] = nd[ND_EXP];
-        nlp[k] = __int_as_float(nd[ND_LP]);
+        tt[k] = table[cc[k]];
+        cb[k] = g.indptr[cc[k]];
+        ce[k] = g.indptr[cc[k] + 1];
       }
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
@@ -589,20 +653,14 @@ __global__ __launch_bounds__(256) void frontier_kernel(EngineDev D, int superste
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           if (j < k && cc[j] == c) dup = true;
-        if (dup) {
-          tt[k] = table[c];
-          if ((int)(tt[k] >> TSG_GEN_SHIFT) == gen) {
-            const int32_t* nd = nodes + (size_t)(tt[k] & TSG_NODE_MASK) * ND_WORDS;
-            nexp[k] = nd[ND_EXP];
-            nlp[k] = __int_as_float(nd[ND_LP]);
-          }
-        }
+        if (dup) tt[k] = table[c];
         // travel time of the expanded road (search.py:376-382); region graphs fall back to a per-pair
         // cost when the region's time distribution is unknown (search.py:1073-1078)
         const int cost = cur_cost >= 0 ? cur_cost : g.pair_cost[(size_t)rid * g.n_roads + c];
         const int next_time = (cur_date_time + cost) % 86400;
         const int tcode_child = next_time / 60 + woff;
-        const uint32_t t = tt[k];
+        const uint32_t t = (uint32_t)tt[k];
+        const float tlp = __uint_as_float((uint32_t)(tt[k] >> 32));  // open: the node's log_prob; closed: +inf
         bool pushed = false;
         int idx = -1;
         if ((int)(t >> TSG_GEN_SHIFT) != gen) {  // c not in rid2node and not in close_set
@@ -611,17 +669,13 @@ __global__ __launch_bounds__(256) void frontier_kernel(EngineDev D, int superste
             continue;
           }
           idx = node_n++;
-          int32_t* nd = nodes + (size_t)idx * ND_WORDS;
-          nd[ND_RID] = c;
-          nd[ND_PARENT] = e;
-          nd[ND_LP] = __float_as_int(lp);
-          nd[ND_DATE_TIME] = next_time;
-          nd[ND_EXP] = ND_OPEN;
-          table[c] = ((uint32_t)gen << TSG_GEN_SHIFT) | (uint32_t)idx;
+          int4* nd = reinterpret_cast<int4*>(nodes + (size_t)idx * ND_WORDS);
+          nd[0] = make_int4(c, e, __float_as_int(lp), next_time);
+          nd[1] = make_int4(ND_OPEN, cb[k], ce[k] - cb[k], child_depth);
           pushed = true;
         } else {
           idx = (int)(t & TSG_NODE_MASK);
-          if (nexp[k] == ND_OPEN && nlp[k] < lp) {  // c in rid2node, strictly better
+          if (tlp < lp) {  // c in rid2node, strictly better
             if (heap_n >= D.e.heap_cap) {
               err = 1;
               continue;
@@ -630,10 +684,12 @@ __global__ __launch_bounds__(256) void frontier_kernel(EngineDev D, int superste
             nd[ND_PARENT] = e;
             nd[ND_LP] = __float_as_int(lp);
             nd[ND_DATE_TIME] = next_time;
+            nd[ND_DEPTH] = child_depth;
             pushed = true;
           }
         }
         if (pushed) {
+          table[c] = (uint64_t)(((uint32_t)gen << TSG_GEN_SHIFT) | (uint32_t)idx) | ((uint64_t)__float_as_uint(lp) << 32);
           HeapEnt he;
           he.prio = -lp;
           he.node = idx;
@@ -641,10 +697,11 @@ __global__ __launch_bounds__(256) void frontier_kernel(EngineDev D, int superste
           // default-length fallback snapshot (search.py:397-402): np.exp(lp) > best_score, best_score starts at 0
           if (child_depth == deflen && lp > best_lp && lp > -745.13f) {
             best_lp = lp;
-            best_parent = e;
-            best_rid = c;
-            best_tcode = tcode_child;
-            have_best = 1;
+            S[SS_BEST_LP] = __float_as_int(lp);
+            S[SS_BEST_PARENT] = e;
+            S[SS_BEST_RID] = c;
+            S[SS_BEST_TCODE] = tcode_child;
+            S[SS_HAVE_BEST] = 1;
           }
         }
       }
@@ -652,8 +709,6 @@ __global__ __launch_bounds__(256) void frontier_kernel(EngineDev D, int superste
     phase = PH_SEARCH;
   }
 
-  CKPT(0);
-  STAMP_ADD(7, 1);
   bool emitted = false;
   int item_depth = 0;
   int pops_here = 0;
@@ -683,8 +738,8 @@ __global__ __launch_bounds__(256) void frontier_kernel(EngineDev D, int superste
       odi = take;
       // ---- start a new search (search.py:255-278)
       ++gen;
-      poff = od.prefix_ptr[odi];
-      plen = od.prefix_ptr[odi + 1] - poff;
+      const int poff = od.prefix_ptr[odi];
+      const int plen = od.prefix_ptr[odi + 1] - poff;
       des = od.des[odi];
       deflen = od.default_len[odi];
       max_step = od.max_step[odi];
@@ -705,12 +760,13 @@ __global__ __launch_bounds__(256) void frontier_kernel(EngineDev D, int superste
         em[(size_t)k * EM_WORDS + EM_DEPTH] = k + 1;
       }
       const int r0 = od.prefix_rid[poff + plen - 1];
-      nodes[ND_RID] = r0;
-      nodes[ND_PARENT] = plen - 2;
-      nodes[ND_LP] = __float_as_int(0.0f);
-      nodes[ND_DATE_TIME] = (start_time - woff) * 60;
-      nodes[ND_EXP] = ND_OPEN;
-      table[r0] = ((uint32_t)gen << TSG_GEN_SHIFT) | 0u;
+      {
+        const int rb = g.indptr[r0], re = g.indptr[r0 + 1];
+        int4* nd = reinterpret_cast<int4*>(nodes);
+        nd[0] = make_int4(r0, plen - 2, __float_as_int(0.0f), (start_time - woff) * 60);
+        nd[1] = make_int4(ND_OPEN, rb, re - rb, plen);
+      }
+      table[r0] = (uint64_t)((uint32_t)gen << TSG_GEN_SHIFT);  // node 0, log_prob 0
       HeapEnt he;
       he.prio = 0.0f;
       he.node = 0;
@@ -719,35 +775,49 @@ __global__ __launch_bounds__(256) void frontier_kernel(EngineDev D, int superste
       node_n = 1;
       exp_n = plen - 1;
       step = 0;
-      have_best = 0;
-      best_lp = -INFINITY;
-      best_parent = -1;
-      best_rid = -1;
-      best_tcode = 0;
       npop = 0;
-      warm_k = 0;
+      S[SS_OD] = odi;
+      S[SS_GEN] = gen;
+      S[SS_WOFF] = woff;
+      S[SS_DES] = des;
+      S[SS_DEFLEN] = deflen;
+      S[SS_MAXSTEP] = max_step;
+      S[SS_ALLOW] = allow;
+      S[SS_WARM_K] = 0;
+      S[SS_PLEN] = plen;
+      S[SS_POFF] = poff;
+      S[SS_HAVE_BEST] = 0;
+      S[SS_BEST_LP] = __float_as_int(-INFINITY);
+      S[SS_BEST_PARENT] = -1;
+      S[SS_BEST_RID] = -1;
+      S[SS_BEST_TCODE] = 0;
       phase = plen > 1 ? PH_WARMUP : PH_SEARCH;
     }
     if (phase == PH_WARMUP) {  // run the recurrent cell over the known prefix, one element per superstep
-      if (!ensure_page(warm_k)) {
+      const int prev_page = last_page;  // page of element k - 1 when it sits in the page before
+      const int k = S[SS_WARM_K], plen = S[SS_PLEN], poff = S[SS_POFF];
+      if (!ensure_page(k)) {
         stall();
         break;
       }
-      const int k = warm_k++;
+      S[SS_WARM_K] = k + 1;
       int32_t* it = itw;
       it[IT_SLOT] = b;
-      it[IT_ROW] = my_pages[k >> TSG_PAGE_SHIFT] * TSG_PAGE_ROWS + (k & (TSG_PAGE_ROWS - 1));
-      it[IT_PROW] = k > 0 ? my_pages[(k - 1) >> TSG_PAGE_SHIFT] * TSG_PAGE_ROWS + ((k - 1) & (TSG_PAGE_ROWS - 1)) : -1;
+      it[IT_ROW] = last_page * TSG_PAGE_ROWS + (k & (TSG_PAGE_ROWS - 1));
+      it[IT_PROW] = k > 0 ? ((k & (TSG_PAGE_ROWS - 1)) ? last_page : prev_page) * TSG_PAGE_ROWS +
+                                ((k - 1) & (TSG_PAGE_ROWS - 1))
+                          : -1;
       it[IT_RID] = od.prefix_rid[poff + k];
       it[IT_TCODE] = od.prefix_time[poff + k];
       it[IT_NCAND] = 0;
       it[IT_DES] = des;
       it[IT_LP] = 0;
       it[IT_DEPTH] = k + 1;
+      *reinterpret_cast<int2*>(D.e.row_meta + 2 * (size_t)it[IT_ROW]) = make_int2(it[IT_RID], it[IT_TCODE]);
       item_depth = k + 1;
-      st_items += 1;
+      st_flags |= 2;
       D.e.page_flags[(b & 255) * 32] = ss_stamp;
-      if (warm_k >= plen - 1) phase = PH_SEARCH;
+      if (k + 1 >= plen - 1) phase = PH_SEARCH;
       emitted = true;
       break;
     }
@@ -756,7 +826,6 @@ __global__ __launch_bounds__(256) void frontier_kernel(EngineDev D, int superste
       stall();
       break;
     }
-    const int row_page = pages_held > (exp_n >> TSG_PAGE_SHIFT) ? my_pages[exp_n >> TSG_PAGE_SHIFT] : 0;
     // ---- PH_SEARCH: pop until a node can be expanded (search.py:279-300)
     int fin_status = -1, fin_parent = -1, fin_rid = -1, fin_tcode = 0, fin_depth = 0;
     bool yielded = false;
@@ -770,17 +839,13 @@ __global__ __launch_bounds__(256) void frontier_kernel(EngineDev D, int superste
         break;
       }
       ++pops_here;
-      CKPT(6);
       const HeapEnt top = heap_pop(heap, heap_n, nodes);
-      CKPT(1);
-      STAMP_ADD(8, 1);
-      int32_t* nd = nodes + (size_t)top.node * ND_WORDS;
-      if (nd[ND_EXP] != ND_OPEN) continue;  // stale duplicate of a closed rid (search.py:284-287)
-      const int rid = nd[ND_RID];
-      const int parent = nd[ND_PARENT];
-      const int date_time = nd[ND_DATE_TIME];
-      const int depth = (parent >= 0 ? em[(size_t)parent * EM_WORDS + EM_DEPTH] : 0) + 1;
-      const int ppage = parent >= 0 ? my_pages[parent >> TSG_PAGE_SHIFT] : 0;  // asked for here, needed when the item is written
+      // the node record: rid, parent, log_prob, date_time | state, CSR row of the road, depth
+      const int4 nd0 = reinterpret_cast<const int4*>(nodes + (size_t)top.node * ND_WORDS)[0];
+      const int4 nd1 = reinterpret_cast<const int4*>(nodes + (size_t)top.node * ND_WORDS)[1];
+      if (nd1.x != ND_OPEN) continue;  // stale duplicate of a closed rid (search.py:284-287)
+      const int rid = nd0.x, parent = nd0.y, nd_lp = nd0.z, date_time = nd0.w;
+      const int beg = nd1.y, C = nd1.z, depth = nd1.w;
       const int tcode = date_time / 60 + woff;
       if (od.poplog_cap > 0 && npop < od.poplog_cap) {
         od.poplog_rid[(size_t)odi * od.poplog_cap + npop] = rid;
@@ -788,7 +853,7 @@ __global__ __launch_bounds__(256) void frontier_kernel(EngineDev D, int superste
       }
       ++npop;
       if (rid == des) {  // search.py:291-297
-        nd[ND_EXP] = ND_CLOSED_NOSLOT;
+        close_node(top.node, rid, ND_CLOSED_NOSLOT);
         fin_status = TSG_STATUS_REACHED;
         fin_parent = parent;
         fin_rid = rid;
@@ -796,26 +861,31 @@ __global__ __launch_bounds__(256) void frontier_kernel(EngineDev D, int superste
         fin_depth = depth;
         break;
       }
-      const int beg = g.indptr[rid];
-      const int C = g.indptr[rid + 1] - beg;
-      const bool gate = C > 0 && (allow < 0 || (g.label && g.label[rid] == allow));  // search.py:300 / :487
-      if (C == 0 && g.empty_key && g.empty_key[rid]) {  // key present, no successors: `continue` (search.py:993-995)
-        nd[ND_EXP] = ND_CLOSED_NOSLOT;
+      // next round trip: the first successors, the parent's page, the road's label and cost
+      int sc[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) sc[k] = C > 0 ? g.indices[beg + (k < C ? k : C - 1)] : 0;
+      const int ppage = parent >= 0 ? my_pages[parent >> TSG_PAGE_SHIFT] : 0;
+      const int lab = (allow >= 0 && g.label) ? g.label[rid] : -1;
+      const int ekey = (C == 0 && g.empty_key) ? g.empty_key[rid] : 0;
+      const int cost = g.cost[(size_t)(date_time / 3600) * g.n_roads + rid];  // search.py:376-381 (<0: per pair)
+      const bool gate = C > 0 && (allow < 0 || (g.label && lab == allow));    // search.py:300 / :487
+      if (ekey) {  // key present, no successors: `continue` (search.py:993-995)
+        close_node(top.node, rid, ND_CLOSED_NOSLOT);
         continue;
       }
       ++step;  // search.py:420
       if (!gate) {
-        nd[ND_EXP] = ND_CLOSED_NOSLOT;
+        close_node(top.node, rid, ND_CLOSED_NOSLOT);
         continue;
       }
-      CKPT(3);
       {  // Expansions that cannot change anything.  The reference still evaluates the model (search.py:359-367)
          // but pushes nothing when every successor is either closed (:388 fails, :403 needs rid2node) or open
          // with a log_prob that no outcome of this evaluation can beat: f = softmax(mix) with every mix_c
          // inside an interval of width s = |1-w1| + |w1| gives f_c <= e^s / (e^s + C - 1).  Nothing pushed
          // means no child will ever need this node's recurrent state, so it is closed without an LSTM step
          // or a scoring pass; results are unchanged.
-        const float lp_node = __int_as_float(nd[ND_LP]);
+        const float lp_node = __int_as_float(nd_lp);
         float ub = lp_node;  // C == 1: the child inherits the log_prob (search.py:305)
         bool use_bound = C == 1;
         if (C > 1 && D.e.prune_spread > 0.0f) {
@@ -825,79 +895,83 @@ __global__ __launch_bounds__(256) void frontier_kernel(EngineDev D, int superste
         }
         bool futile = true;
         for (int i0 = 0; i0 < C && futile; i0 += 4) {
-          uint32_t tt[4];
-#pragma unroll
-          for (int k = 0; k < 4; ++k) tt[k] = table[g.indices[beg + (i0 + k < C ? i0 + k : C - 1)]];
+          uint64_t tq[4];
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
-            const bool seen = (int)(tt[k] >> TSG_GEN_SHIFT) == gen;
-            const int32_t* q = nodes + (size_t)(seen ? (tt[k] & TSG_NODE_MASK) : 0) * ND_WORDS;
-            const int qexp = q[ND_EXP];
-            const float qlp = __int_as_float(q[ND_LP]);
-            const bool dead = seen && (qexp != ND_OPEN || (use_bound && qlp >= ub));
+            const int i = i0 + k < C ? i0 + k : C - 1;
+            const int s = i0 == 0 ? sc[k] : g.indices[beg + i];
+            tq[k] = table[s];
+          }
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const bool seen = (int)((uint32_t)tq[k] >> TSG_GEN_SHIFT) == gen;
+            const float qlp = __uint_as_float((uint32_t)(tq[k] >> 32));  // +inf: closed
+            const bool dead = seen && (use_bound ? qlp >= ub : qlp == INFINITY);
             if (!dead) futile = false;
           }
         }
         if (futile) {
-          nd[ND_EXP] = ND_CLOSED_NOSLOT;
-          st_skipped += 1;
-          CKPT(9);
+          close_node(top.node, rid, ND_CLOSED_NOSLOT);
+          st_flags += 256;
           continue;
         }
       }
-      CKPT(4);
       if (exp_n >= D.e.exp_cap) {
         err = 1;
         break;
       }
       const int e = exp_n++;
-      nd[ND_EXP] = e;
-      em[(size_t)e * EM_WORDS + EM_PARENT] = parent;
-      em[(size_t)e * EM_WORDS + EM_RID] = rid;
-      em[(size_t)e * EM_WORDS + EM_TCODE] = tcode;
-      em[(size_t)e * EM_WORDS + EM_DEPTH] = depth;
-      const int hour = date_time / 3600;                                   // search.py:376
-      const int cost = g.cost[(size_t)hour * g.n_roads + rid];              // search.py:377-381 (pre-resolved; <0: per pair)
+      close_node(top.node, rid, e);
+      *reinterpret_cast<int4*>(em + (size_t)e * EM_WORDS) = make_int4(parent, rid, tcode, depth);
+      // the successor list, for the distance and scoring kernels and for the relaxation in the next superstep
+      for (int i0 = 0; i0 < C; i0 += 4) {
+        int s[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s[k] = i0 == 0 ? sc[k] : g.indices[beg + (i0 + k < C ? i0 + k : C - 1)];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (i0 + k < C) D.e.cand_id[(size_t)b * md + i0 + k] = s[k];
+      }
       S[SS_CUR_EXP] = e;
       S[SS_CUR_RID] = rid;
       S[SS_CUR_C] = C;
       S[SS_CUR_DATE_TIME] = date_time;
       S[SS_CUR_COST] = cost;
-      S[SS_CUR_LP] = nd[ND_LP];
+      S[SS_CUR_LP] = nd_lp;
       S[SS_CUR_DEPTH] = depth;
       if (C > 1) {  // per-slot statistics (summed on the host; no same-address atomics on the hot path)
-        st_evals += 1;
-        st_cand += C;
-        st_chain += depth;
+        st_flags |= 1;
+        st_cand = C;
+        st_chain = depth;
       }
       int32_t* it = itw;
       it[IT_SLOT] = b;
-      it[IT_ROW] = row_page * TSG_PAGE_ROWS + (e & (TSG_PAGE_ROWS - 1));
-      st_items += 1;
+      it[IT_ROW] = last_page * TSG_PAGE_ROWS + (e & (TSG_PAGE_ROWS - 1));
+      st_flags |= 2;
       it[IT_PROW] = parent >= 0 ? ppage * TSG_PAGE_ROWS + (parent & (TSG_PAGE_ROWS - 1)) : -1;
       it[IT_RID] = rid;
       it[IT_TCODE] = tcode;
       it[IT_NCAND] = C;
       it[IT_DES] = des;
-      it[IT_LP] = nd[ND_LP];
+      it[IT_LP] = nd_lp;
       it[IT_DEPTH] = depth;
+      *reinterpret_cast<int2*>(D.e.row_meta + 2 * (size_t)it[IT_ROW]) = make_int2(rid, tcode);
       item_depth = C > 1 ? depth : 0;  // single-successor expansions are not scored: short
       D.e.page_flags[(b & 255) * 32] = ss_stamp;
       phase = PH_EXPANDED;
       emitted = true;
-      CKPT(5);
       break;
     }
     if (emitted || err) break;
     if (yielded) break;
-    CKPT(10);
     // ---- the search is over (search.py:421-424): destination popped, queue empty, or budget spent
     if (fin_status < 0) {
-      if (have_best) {
+      const int plen = S[SS_PLEN], poff = S[SS_POFF];
+      if (S[SS_HAVE_BEST]) {
         fin_status = TSG_STATUS_FALLBACK;
-        fin_parent = best_parent;
-        fin_rid = best_rid;
-        fin_tcode = best_tcode;
+        fin_parent = S[SS_BEST_PARENT];
+        fin_rid = S[SS_BEST_RID];
+        fin_tcode = S[SS_BEST_TCODE];
         fin_depth = deflen;
       } else {
         fin_status = TSG_STATUS_UNTOUCHED;
@@ -910,8 +984,10 @@ __global__ __launch_bounds__(256) void frontier_kernel(EngineDev D, int superste
     {
       const int lmax = od.lmax;
       if (fin_depth > lmax) fin_status |= TSG_STATUS_OVERFLOW;
-      write_path(em, fin_parent, fin_rid, fin_tcode, fin_depth, od.out_rid + (size_t)odi * lmax,
-                 od.out_time + (size_t)odi * lmax, lmax);
+      const int parent_row =
+          fin_parent >= 0 ? my_pages[fin_parent >> TSG_PAGE_SHIFT] * TSG_PAGE_ROWS + (fin_parent & (TSG_PAGE_ROWS - 1)) : -1;
+      write_path_rows(D.e, parent_row, fin_rid, fin_tcode, fin_depth, od.out_rid + (size_t)odi * lmax,
+                      od.out_time + (size_t)odi * lmax, lmax);
       od.out_len[odi] = fin_depth;
       od.out_status[odi] = fin_status;
       od.out_steps[odi] = step;
@@ -922,7 +998,6 @@ __global__ __launch_bounds__(256) void frontier_kernel(EngineDev D, int superste
     release_pages();
     D.e.page_flags[(b & 255) * 32] = ss_stamp;
     phase = PH_IDLE;
-    CKPT(11);
   }
   if (err) {
     // a workspace cap was hit: report, finish the OD as OVERFLOW so that the batch still terminates
@@ -967,39 +1042,24 @@ __global__ __launch_bounds__(256) void frontier_kernel(EngineDev D, int superste
       }
     }
   }
-  CKPT(2);
-#if TSG_STAMP
-  for (int i = 0; i < 16; ++i)
-    if (st_acc[i]) atomicAdd(&g_stamp[i], (unsigned long long)st_acc[i]);
-#endif
+  // slot state back (the words kept in registers) and the statistics (per-slot words summed on the host: no
+  // same-address atomics on the hot path; nobody waits for these)
   S[SS_PHASE] = phase;
-  S[SS_OD] = odi;
   S[SS_STEP] = step;
   S[SS_HEAP_N] = heap_n;
   S[SS_NODE_N] = node_n;
   S[SS_EXP_N] = exp_n;
-  S[SS_GEN] = gen;
-  S[SS_WOFF] = woff;
-  S[SS_DES] = des;
-  S[SS_DEFLEN] = deflen;
-  S[SS_MAXSTEP] = max_step;
-  S[SS_ALLOW] = allow;
-  S[SS_WARM_K] = warm_k;
-  S[SS_PLEN] = plen;
-  S[SS_POFF] = poff;
-  S[SS_BEST_LP] = __float_as_int(best_lp);
-  S[SS_BEST_PARENT] = best_parent;
-  S[SS_BEST_RID] = best_rid;
-  S[SS_BEST_TCODE] = best_tcode;
-  S[SS_HAVE_BEST] = have_best;
   S[SS_NPOP] = npop;
-  S[SS_ST_EVALS] = st_evals;
-  S[SS_ST_CAND] = st_cand;
-  S[SS_ST_CHAIN] = st_chain;
-  S[SS_ST_SKIPPED] = st_skipped;
-  S[SS_ST_ITEMS] = st_items;
-  S[SS_ST_STALLS] = st_stalls;
   S[SS_PAGES] = pages_held;
+  S[SS_LAST_PAGE] = last_page;
+  if (st_flags & 1) {
+    atomicAdd(&S[SS_ST_EVALS], 1);
+    atomicAdd(&S[SS_ST_CAND], st_cand);
+    atomicAdd(&S[SS_ST_CHAIN], st_chain);
+  }
+  if (st_flags & 2) atomicAdd(&S[SS_ST_ITEMS], 1);
+  if (st_flags & 4) atomicAdd(&S[SS_ST_STALLS], 1);
+  if (st_flags >> 8) atomicAdd(&S[SS_ST_SKIPPED], st_flags >> 8);
 }
 
 // =====================================================================================
@@ -1015,7 +1075,10 @@ static int check_engine(const tsg_model* m, const tsg_graph* g, const tsg_od_bat
   const size_t B = (size_t)e->slots;
   if (!e->slot_state || e->slot_state_bytes < B * SS_WORDS * 4) return TSG_E_TOO_SMALL;
   if (!e->heap || e->heap_bytes < B * e->heap_cap * 8) return TSG_E_TOO_SMALL;
-  if (!e->table || e->table_bytes < B * (size_t)g->n_roads * 4) return TSG_E_TOO_SMALL;
+  if (!e->table || e->table_bytes < B * (size_t)g->n_roads * 8) return TSG_E_TOO_SMALL;
+  if (!e->cand_id || e->cand_id_bytes < B * (size_t)g->max_degree * 4) return TSG_E_TOO_SMALL;
+  if (!e->exp_up || e->exp_up_bytes < (size_t)e->n_pages * TSG_PAGE_ROWS * TSG_UP_LEVELS * 4) return TSG_E_TOO_SMALL;
+  if (!e->row_meta || e->row_meta_bytes < (size_t)e->n_pages * TSG_PAGE_ROWS * 8) return TSG_E_TOO_SMALL;
   if (!e->nodes || e->nodes_bytes < B * e->node_cap * ND_WORDS * 4) return TSG_E_TOO_SMALL;
   if (!e->exp_meta || e->exp_meta_bytes < B * e->exp_cap * EM_WORDS * 4) return TSG_E_TOO_SMALL;
   if (!e->items || e->items_bytes < tsg_item_positions(e->slots) * IT_WORDS * 4) return TSG_E_TOO_SMALL;
@@ -1065,7 +1128,7 @@ extern "C" int tsg_engine_reset(const tsg_engine* e, const tsg_graph* g, void* s
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
   TSG_HIP_TRY(hipMemsetAsync(e->slot_state, 0, (size_t)e->slots * SS_WORDS * 4, s));  // phase IDLE, gen 0
-  TSG_HIP_TRY(hipMemsetAsync(e->table, 0, (size_t)e->slots * g->n_roads * 4, s));
+  TSG_HIP_TRY(hipMemsetAsync(e->table, 0, (size_t)e->slots * g->n_roads * 8, s));
   TSG_HIP_TRY(hipMemsetAsync(e->page_flags, 0, 2 * TSG_FLAG_PLANE * 4, s));
   TSG_HIP_TRY(hipMemsetAsync(e->items, 0, tsg_item_positions(e->slots) * IT_WORDS * 4, s));
   TSG_HIP_TRY(hipMemsetAsync(e->item_counts, 0, tsg_item_count_words(e->slots) * 4, s));

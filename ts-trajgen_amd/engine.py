@@ -413,7 +413,7 @@ class AStarEngine(object):
         rows = self.n_pages * self.PAGE_ROWS
         self.slot_state = torch.zeros((B, 40), dtype=i32, device=dev)
         self.heap = torch.empty((B, self.heap_cap), dtype=torch.int64, device=dev)
-        self.table = torch.zeros((B, n), dtype=i32, device=dev)
+        self.table = torch.zeros((B, n), dtype=torch.int64, device=dev)
         self.nodes = torch.empty((B, self.node_cap, 8), dtype=i32, device=dev)
         self.exp_meta = torch.empty((B, self.exp_cap, 4), dtype=i32, device=dev)
         self.up_levels = 64     # TSG_UP_LEVELS: ancestors listed per expanded node
@@ -430,10 +430,13 @@ class AStarEngine(object):
         self.items = torch.zeros((nreg * 4096, 12), dtype=i32, device=dev)
         self.item_counts = torch.zeros((2, nreg, 32), dtype=i32, device=dev)
         self.cand_lp = torch.empty((B, graph.max_degree), dtype=f32, device=dev)
+        self.cand_id = torch.zeros((B, graph.max_degree), dtype=i32, device=dev)
+        self.row_meta = torch.empty((rows, 2), dtype=i32, device=dev)
         self.counters = torch.zeros((2, 16), dtype=i32, device=dev)   # row 0: page control, row 1: OD queue / totals
         e = _lib.Engine()
         e.slots, e.exp_cap, e.node_cap, e.heap_cap = B, self.exp_cap, self.node_cap, self.heap_cap
-        for name in ('slot_state', 'heap', 'table', 'nodes', 'exp_meta', 'exp_up', 'items', 'item_counts', 'cand_lp', 'slot_pages',
+        for name in ('slot_state', 'heap', 'table', 'nodes', 'exp_meta', 'exp_up', 'items', 'item_counts', 'cand_lp', 'cand_id',
+                     'row_meta', 'slot_pages',
                      'page_ring', 'page_flags'):
             t = getattr(self, name)
             setattr(e, name, t.data_ptr())
@@ -466,13 +469,13 @@ class AStarEngine(object):
         node_cap = min(graph.num_roads, 1 + max_step * graph.max_degree) + 1
         heap_cap = 1 + max_step * graph.max_degree
         pps = (exp_cap + 63) // 64
-        return heap_cap * 8 + graph.num_roads * 4 + node_cap * 32 + exp_cap * 16 + pps * 4 + 40 * 4 + 48 \
-            + graph.max_degree * 4
+        return heap_cap * 8 + graph.num_roads * 8 + node_cap * 32 + exp_cap * 16 + pps * 4 + 40 * 4 + 48 \
+            + graph.max_degree * 8
 
     @staticmethod
     def bytes_per_page(tables):
         """One state page: 64 rows of (h, c) per layer + the 64-entry ancestor list of each row."""
-        return 64 * (2 * tables.n_layers * tables.hp * 4 + 64 * 4)
+        return 64 * (2 * tables.n_layers * tables.hp * 4 + 64 * 4 + 8)
 
     @staticmethod
     def bytes_per_slot(tables, graph, max_step, max_prefix=1):
