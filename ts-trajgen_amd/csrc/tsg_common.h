@@ -46,9 +46,13 @@ enum {
   SS_CUR_LP, SS_BEST_LP, SS_BEST_PARENT, SS_BEST_RID, SS_BEST_TCODE, SS_HAVE_BEST, SS_NPOP, SS_POFF,
   SS_CUR_DEPTH, SS_ST_EVALS, SS_ST_CAND, SS_ST_CHAIN, SS_CUR_COST, SS_ST_SKIPPED, SS_ST_ITEMS, SS_PAGES, SS_ST_STALLS,
   SS_LAST_PAGE,  // the state page taken last (= the page of the next expansion's row once ensure_page succeeded)
+  SS_FIN_STATUS, SS_FIN_PARENT, SS_FIN_RID, SS_FIN_TCODE,  // PH_FINISH: the result (its length is parked in SS_CUR_DEPTH)
   SS_WORDS = 40
 };
-enum { PH_IDLE = 0, PH_WARMUP = 1, PH_SEARCH = 2, PH_EXPANDED = 3, PH_DONE = 4 };
+// PH_FINISH: the search is over and its result is parked in the slot (SS_FIN_*); the next superstep writes the
+// trajectory and returns the pages, the one after admits a new OD pair: the long chains of a superstep (pops until
+// the destination, the write-out, the start of a search) never follow each other inside one launch
+enum { PH_IDLE = 0, PH_WARMUP = 1, PH_SEARCH = 2, PH_EXPANDED = 3, PH_DONE = 4, PH_FINISH = 5 };
 // shared counters (tsg_engine.shared_counters)
 enum { CT_ITEMS0 = 0, CT_ITEMS1 = 1, CT_NEXT_OD = 2, CT_FINISHED = 3, CT_EXPANSIONS = 4, CT_MODEL_EVALS = 5, CT_ERROR = 6, CT_ITEMS_TOTAL = 7 };
 // state-page control words (tsg_engine.counters): free ring [head, tail) of page ids, retry ring of aborted OD

@@ -316,29 +316,39 @@ __device__ __forceinline__ HeapEnt ent_of(uint64_t v) {
   return e;
 }
 // heapq.heappush == append + _siftdown(heap, 0, len-1).  The ancestors of the insertion point have known
-// addresses, so four of them are fetched per round trip instead of one.
-__device__ __forceinline__ void heap_push(uint64_t* h, int& n, HeapEnt item, const int32_t* nodes) {
+// addresses ((pos + 1) >> k) - 1, so TSG_PUSH_ANC of them are fetched per round trip instead of one.  (A push climbs
+// 0.35 levels on average; what a round trip costs grows with the number of cache lines it asks for, so fetching
+// all ancestors at once is no faster than four: ablate/chase_k.hip, DESIGN.md.)
+#ifndef TSG_PUSH_ANC
+#define TSG_PUSH_ANC 4
+#endif
+#if TSG_STAMP
+__device__ int g_cnt_dummy;
+#define HCNT(x) (x)
+#else
+#define HCNT(x)
+#endif
+__device__ __forceinline__ void heap_push(uint64_t* h, int& n, HeapEnt item, const int32_t* nodes, int* moves = nullptr) {
   int pos = n++;
   while (pos > 0) {
-    int ai[4];
-    uint64_t av[4];
-    int p = pos;
+    uint64_t av[TSG_PUSH_ANC];
+    const int base = pos + 1;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      p = p > 0 ? (p - 1) >> 1 : 0;
-      ai[k] = p;
-      av[k] = h[p];
+    for (int k = 0; k < TSG_PUSH_ANC; ++k) {
+      const int a = (base >> (k + 1)) - 1;
+      av[k] = h[a > 0 ? a : 0];
     }
     bool stop = false;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < TSG_PUSH_ANC; ++k) {
       if (stop || pos == 0) continue;
       const HeapEnt par = ent_of(av[k]);
       if (!ent_less(item, par, nodes)) {
         stop = true;
       } else {
         heap_st(h, pos, par);
-        pos = ai[k];
+        pos = (base >> (k + 1)) - 1;
+        if (moves) ++*moves;
       }
     }
     if (stop) break;
@@ -514,6 +524,19 @@ __device__ __forceinline__ void write_path_rows(const tsg_engine& e, int parent_
 #define TSG_FRONTIER_WPB 4
 #endif
 static_assert(TSG_REGION_SLOTS % TSG_SPW == 0, "the searches of a wave share one region of the work list");
+#if TSG_STAMP
+__device__ unsigned long long g_stamp[32768 * 32];  // one record per search slot, of the superstep TSG_STAMP_AT
+#define CKPT(i) { const long long _n = clock64(); st_acc[i] += _n - st_last; st_last = _n; }
+#define STAMP_ADD(i, v) st_acc[i] += (long long)(v)
+extern "C" int tsg_debug_read_stamps(unsigned long long* out_host, int reset) {
+  (void)reset;
+  if (hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_stamp), sizeof(g_stamp)) != hipSuccess) return -1;
+  return 0;
+}
+#else
+#define CKPT(i)
+#define STAMP_ADD(i, v)
+#endif
 __global__ __launch_bounds__(256) void frontier_kernel(EngineDev D, int superstep) {
   const int b = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * TSG_SPW + (threadIdx.x & 63);
   if (b >= D.e.slots || (threadIdx.x & 63) >= TSG_SPW) return;
@@ -542,8 +565,14 @@ __global__ __launch_bounds__(256) void frontier_kernel(EngineDev D, int superste
   // the word during this launch
   if (b == 0) pc[PC_ITEM_PLANE] = ss_now & 1;
   const int* sv = reinterpret_cast<const int*>(sq);
+#if TSG_STAMP
+  long long st_acc[32] = {0};
+  const long long st_t0 = clock64();
+  long long st_last = st_t0;
+#endif
   int phase = sv[SS_PHASE];
   if (phase == PH_DONE) return;
+  CKPT(0);  // first round trip
   int32_t itw[IT_WORDS] = {0};  // the work item of this superstep, if one is emitted: written to the work list at the end
   int32_t* shared = D.e.shared_counters;  // OD queue + completion, common to all sub-engines of a batch
   uint64_t* heap = D.e.heap + (size_t)b * D.e.heap_cap;
@@ -660,6 +689,9 @@ __global__ __launch_bounds__(256) void frontier_kernel(EngineDev D, int superste
         const int next_time = (cur_date_time + cost) % 86400;
         const int tcode_child = next_time / 60 + woff;
         const uint32_t t = (uint32_t)tt[k];
+#if TSG_STAMP
+        if (k == 0 && i0 == 0 && t != 0xffffffffu) CKPT(16);  // table entries arrived
+#endif
         const float tlp = __uint_as_float((uint32_t)(tt[k] >> 32));  // open: the node's log_prob; closed: +inf
         bool pushed = false;
         int idx = -1;
@@ -693,7 +725,11 @@ __global__ __launch_bounds__(256) void frontier_kernel(EngineDev D, int superste
           HeapEnt he;
           he.prio = -lp;
           he.node = idx;
+#if TSG_STAMP
+          { int _mv = 0; const long long _a = clock64(); heap_push(heap, heap_n, he, nodes, &_mv); st_acc[19] += _mv; st_acc[20] += heap_n; const long long _b = clock64(); st_acc[17] += _b - _a; st_acc[18] += 1; st_last = _b; }
+#else
           heap_push(heap, heap_n, he, nodes);
+#endif
           // default-length fallback snapshot (search.py:397-402): np.exp(lp) > best_score, best_score starts at 0
           if (child_depth == deflen && lp > best_lp && lp > -745.13f) {
             best_lp = lp;
@@ -707,12 +743,36 @@ __global__ __launch_bounds__(256) void frontier_kernel(EngineDev D, int superste
       }
     }
     phase = PH_SEARCH;
+    CKPT(1);  // relax
+    STAMP_ADD(12, 1);
   }
 
   bool emitted = false;
   int item_depth = 0;
   int pops_here = 0;
-  while (!emitted && !err) {
+  bool wrote_out = false;
+  if (phase == PH_FINISH) {  // the search ended in the previous superstep: write its result, give the pages back
+    int fin_status = sv[SS_FIN_STATUS];
+    const int fin_parent = sv[SS_FIN_PARENT], fin_rid = sv[SS_FIN_RID], fin_tcode = sv[SS_FIN_TCODE];
+    const int fin_depth = sv[SS_CUR_DEPTH];
+    const int lmax = od.lmax;
+    if (fin_depth > lmax) fin_status |= TSG_STATUS_OVERFLOW;
+    const int parent_row =
+        fin_parent >= 0 ? my_pages[fin_parent >> TSG_PAGE_SHIFT] * TSG_PAGE_ROWS + (fin_parent & (TSG_PAGE_ROWS - 1)) : -1;
+    write_path_rows(D.e, parent_row, fin_rid, fin_tcode, fin_depth, od.out_rid + (size_t)odi * lmax,
+                    od.out_time + (size_t)odi * lmax, lmax);
+    od.out_len[odi] = fin_depth;
+    od.out_status[odi] = fin_status;
+    od.out_steps[odi] = step;
+    if (od.poplog_n) od.poplog_n[odi] = npop;
+    atomicAdd(&shared[CT_EXPANSIONS], step);
+    atomicAdd(&shared[CT_FINISHED], 1);
+    release_pages();
+    D.e.page_flags[(b & 255) * 32] = ss_stamp;
+    phase = PH_IDLE;
+    wrote_out = true;
+  }
+  while (!emitted && !err && !wrote_out) {
     if (phase == PH_IDLE) {
       if (gen >= TSG_GEN_MAX) {  // table generation space exhausted for this slot: stop refilling it
         phase = PH_DONE;
@@ -839,10 +899,14 @@ __global__ __launch_bounds__(256) void frontier_kernel(EngineDev D, int superste
         break;
       }
       ++pops_here;
+      CKPT(2);
       const HeapEnt top = heap_pop(heap, heap_n, nodes);
+      CKPT(3);  // pop
+      STAMP_ADD(13, 1);
       // the node record: rid, parent, log_prob, date_time | state, CSR row of the road, depth
       const int4 nd0 = reinterpret_cast<const int4*>(nodes + (size_t)top.node * ND_WORDS)[0];
       const int4 nd1 = reinterpret_cast<const int4*>(nodes + (size_t)top.node * ND_WORDS)[1];
+      CKPT(4);  // node record
       if (nd1.x != ND_OPEN) continue;  // stale duplicate of a closed rid (search.py:284-287)
       const int rid = nd0.x, parent = nd0.y, nd_lp = nd0.z, date_time = nd0.w;
       const int beg = nd1.y, C = nd1.z, depth = nd1.w;
@@ -870,6 +934,7 @@ __global__ __launch_bounds__(256) void frontier_kernel(EngineDev D, int superste
       const int ekey = (C == 0 && g.empty_key) ? g.empty_key[rid] : 0;
       const int cost = g.cost[(size_t)(date_time / 3600) * g.n_roads + rid];  // search.py:376-381 (<0: per pair)
       const bool gate = C > 0 && (allow < 0 || (g.label && lab == allow));    // search.py:300 / :487
+      CKPT(5);  // successors etc
       if (ekey) {  // key present, no successors: `continue` (search.py:993-995)
         close_node(top.node, rid, ND_CLOSED_NOSLOT);
         continue;
@@ -910,6 +975,7 @@ __global__ __launch_bounds__(256) void frontier_kernel(EngineDev D, int superste
             if (!dead) futile = false;
           }
         }
+        CKPT(6);  // table
         if (futile) {
           close_node(top.node, rid, ND_CLOSED_NOSLOT);
           st_flags += 256;
@@ -960,6 +1026,7 @@ __global__ __launch_bounds__(256) void frontier_kernel(EngineDev D, int superste
       D.e.page_flags[(b & 255) * 32] = ss_stamp;
       phase = PH_EXPANDED;
       emitted = true;
+      CKPT(7);  // expansion stores
       break;
     }
     if (emitted || err) break;
@@ -981,23 +1048,14 @@ __global__ __launch_bounds__(256) void frontier_kernel(EngineDev D, int superste
         fin_depth = plen;
       }
     }
-    {
-      const int lmax = od.lmax;
-      if (fin_depth > lmax) fin_status |= TSG_STATUS_OVERFLOW;
-      const int parent_row =
-          fin_parent >= 0 ? my_pages[fin_parent >> TSG_PAGE_SHIFT] * TSG_PAGE_ROWS + (fin_parent & (TSG_PAGE_ROWS - 1)) : -1;
-      write_path_rows(D.e, parent_row, fin_rid, fin_tcode, fin_depth, od.out_rid + (size_t)odi * lmax,
-                      od.out_time + (size_t)odi * lmax, lmax);
-      od.out_len[odi] = fin_depth;
-      od.out_status[odi] = fin_status;
-      od.out_steps[odi] = step;
-      if (od.poplog_n) od.poplog_n[odi] = npop;
-      atomicAdd(&shared[CT_EXPANSIONS], step);
-      atomicAdd(&shared[CT_FINISHED], 1);
-    }
-    release_pages();
+    S[SS_FIN_STATUS] = fin_status;
+    S[SS_FIN_PARENT] = fin_parent;
+    S[SS_FIN_RID] = fin_rid;
+    S[SS_FIN_TCODE] = fin_tcode;
+    S[SS_CUR_DEPTH] = fin_depth;
     D.e.page_flags[(b & 255) * 32] = ss_stamp;
-    phase = PH_IDLE;
+    phase = PH_FINISH;
+    break;
   }
   if (err) {
     // a workspace cap was hit: report, finish the OD as OVERFLOW so that the batch still terminates
@@ -1042,6 +1100,11 @@ __global__ __launch_bounds__(256) void frontier_kernel(EngineDev D, int superste
       }
     }
   }
+  CKPT(8);  // emit (work-list atomic)
+#if TSG_STAMP
+  st_acc[9] = clock64() - st_t0; st_acc[14] = 1; st_acc[15] = st_t0; st_acc[11] = wall_clock64();
+  if (ss_now == TSG_STAMP_AT && b < 32768) for (int i = 0; i < 32; ++i) g_stamp[(size_t)b * 32 + i] = (unsigned long long)st_acc[i];
+#endif
   // slot state back (the words kept in registers) and the statistics (per-slot words summed on the host: no
   // same-address atomics on the hot path; nobody waits for these)
   S[SS_PHASE] = phase;

@@ -589,7 +589,7 @@ class AStarEngine(object):
             stream.wait_stream(main)
             _lib.check(L.tsg_engine_reset(C.byref(eng), C.byref(g), handle), 'tsg_engine_reset')
             # every superstep each unfinished slot advances by >= 1 expansion / prefix element / finished OD
-            per_search = self.max_step + self.max_prefix + 2
+            per_search = self.max_step + self.max_prefix + 4    # + the write-out superstep and the idle one behind it
             if self.max_pops > 0:       # yields: at most heap_cap pops per search, max_pops of them per superstep
                 per_search += self.heap_cap // self.max_pops + 1
             bound = (math.ceil(n_od / self.slots) + 1) * per_search + 8 + self.ramp_steps
