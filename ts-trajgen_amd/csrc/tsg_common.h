@@ -35,6 +35,31 @@ __device__ __forceinline__ float tsg_wave_max(float v) {
   return v;
 }
 
+// The same reductions without the LDS crossbar (ds_bpermute): four DPP steps inside each row of 16 lanes (quad
+// swaps, half-row and row mirrors: v_add_f32 ... dpp), then the four row totals are read as scalars.  The result is
+// wave-uniform; all 64 lanes must be active.
+template <int CTRL>
+__device__ __forceinline__ float tsg_dpp(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float tsg_lane_value(float v, int l) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+__device__ __forceinline__ float tsg_wave_sum_u(float v) {
+  v += tsg_dpp<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += tsg_dpp<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += tsg_dpp<0x141>(v);  // row_half_mirror
+  v += tsg_dpp<0x140>(v);  // row_mirror
+  return (tsg_lane_value(v, 0) + tsg_lane_value(v, 16)) + (tsg_lane_value(v, 32) + tsg_lane_value(v, 48));
+}
+__device__ __forceinline__ float tsg_wave_max_u(float v) {
+  v = fmaxf(v, tsg_dpp<0xB1>(v));
+  v = fmaxf(v, tsg_dpp<0x4E>(v));
+  v = fmaxf(v, tsg_dpp<0x141>(v));
+  v = fmaxf(v, tsg_dpp<0x140>(v));
+  return fmaxf(fmaxf(tsg_lane_value(v, 0), tsg_lane_value(v, 16)), fmaxf(tsg_lane_value(v, 32), tsg_lane_value(v, 48)));
+}
+
 // v_exp_f32 / v_rcp_f32 forms (about 1e-7 absolute error, far inside the 1e-4 parity budget)
 __device__ __forceinline__ float tsg_sigmoid(float x) { return __frcp_rn(1.0f + __expf(-x)); }
 __device__ __forceinline__ float tsg_tanh(float x) { return 1.0f - 2.0f * __frcp_rn(1.0f + __expf(2.0f * x)); }

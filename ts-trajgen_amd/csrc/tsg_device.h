@@ -128,10 +128,7 @@ __device__ __forceinline__ void attn_fold4(AttnAcc<JT>& s, float key[4][JT], uns
     for (int j = 0; j < JT; ++j) part[u] += key[u][j] * q[j];
   }
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-#pragma unroll
-    for (int u = 0; u < 4; ++u) part[u] += __shfl_xor(part[u], o, TSG_WAVE);
-  }
+  for (int u = 0; u < 4; ++u) part[u] = tsg_wave_sum_u(part[u]);
   float mn = s.m;
 #pragma unroll
   for (int u = 0; u < 4; ++u)
@@ -173,16 +170,16 @@ __device__ __forceinline__ float tsg_h_logit(const tsg_model& m, int cand, int d
 __device__ __forceinline__ float tsg_mix_softmax(const tsg_model& m, float g_logit, float h_logit, bool on, float* pg,
                                                  float* ph) {
   const float w1 = m.hparams[41];
-  const float gmax = tsg_wave_max(on ? g_logit : -INFINITY);
+  const float gmax = tsg_wave_max_u(on ? g_logit : -INFINITY);
   const float ge = on ? expf(g_logit - gmax) : 0.0f;
-  const float g = ge / tsg_wave_sum(ge);
-  const float hmax = tsg_wave_max(on ? h_logit : -INFINITY);
+  const float g = ge / tsg_wave_sum_u(ge);
+  const float hmax = tsg_wave_max_u(on ? h_logit : -INFINITY);
   const float he = on ? expf(h_logit - hmax) : 0.0f;
-  const float h = he / tsg_wave_sum(he);
+  const float h = he / tsg_wave_sum_u(he);
   const float mix = on ? (1.0f - w1) * g + w1 * h : -INFINITY;
-  const float mmax = tsg_wave_max(mix);
+  const float mmax = tsg_wave_max_u(mix);
   const float me = on ? expf(mix - mmax) : 0.0f;
-  const float f = me / tsg_wave_sum(me);
+  const float f = me / tsg_wave_sum_u(me);
   if (pg) *pg = g;
   if (ph) *ph = h;
   return f;
@@ -212,10 +209,7 @@ __device__ __forceinline__ float score_row(const tsg_model& m, const float poole
       for (int j = 0; j < JT; ++j) part[u] += w[j] * pooled[j];
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-#pragma unroll
-      for (int u = 0; u < 4; ++u) part[u] += __shfl_xor(part[u], o, TSG_WAVE);
-    }
+    for (int u = 0; u < 4; ++u) part[u] = tsg_wave_sum_u(part[u]);
 #pragma unroll
     for (int u = 0; u < 4; ++u)
       if (lane == c0 + u && c0 + u < ncand) g_logit = part[u] + m.out_b[cid[u]];
