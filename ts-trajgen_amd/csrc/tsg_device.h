@@ -152,6 +152,59 @@ __device__ __forceinline__ void attn_fold4(AttnAcc<JT>& s, float key[4][JT], uns
   s.m = mn;
 }
 
+// The same in groups of N rows (the engine's scoring kernel keeps two groups of eight in flight).
+template <int JT, int N>
+__device__ __forceinline__ void attn_load_n(float key[N][JT], const float* const rows[N], int J, int lane) {
+#pragma unroll
+  for (int u = 0; u < N; ++u) {
+    if (rows[u]) {
+      load_row<JT>(rows[u], key[u], J, lane);
+    } else {
+#pragma unroll
+      for (int j = 0; j < JT; ++j) key[u][j] = 0.0f;
+    }
+  }
+}
+
+template <int JT, int N, bool SPLIT = false>
+__device__ __forceinline__ void attn_fold_n(AttnAcc<JT>& s, float key[N][JT], unsigned present, const float q[JT]) {
+  if (SPLIT) {  // decode in place
+#pragma unroll
+    for (int u = 0; u < N; ++u)
+#pragma unroll
+      for (int j = 0; j < JT; ++j) key[u][j] = tsg_state_value(key[u][j]);
+  }
+  float part[N];
+#pragma unroll
+  for (int u = 0; u < N; ++u) {
+    float p = 0.0f;
+#pragma unroll
+    for (int j = 0; j < JT; ++j) p += key[u][j] * q[j];
+    part[u] = tsg_wave_sum_u(p);
+  }
+  float mn = s.m;
+#pragma unroll
+  for (int u = 0; u < N; ++u)
+    if (present & (1u << u)) mn = fmaxf(mn, part[u]);
+  const float scale = __expf(s.m - mn);  // exp(-inf) = 0 on the first fold
+  float w[N];
+  float wsum = 0.0f;
+#pragma unroll
+  for (int u = 0; u < N; ++u) {
+    w[u] = (present & (1u << u)) ? __expf(part[u] - mn) : 0.0f;
+    wsum += w[u];
+  }
+  s.l = s.l * scale + wsum;
+#pragma unroll
+  for (int j = 0; j < JT; ++j) {
+    float a = s.v[j] * scale;
+#pragma unroll
+    for (int u = 0; u < N; ++u) a += w[u] * key[u][j];
+    s.v[j] = a;
+  }
+  s.m = mn;
+}
+
 // H logit of one candidate: factored emb_fc + dis_fc + out_fc (distance_gat_fc.py:129-133)
 __device__ __forceinline__ float tsg_h_logit(const tsg_model& m, int cand, int des, float dis) {
   const float* hpar = m.hparams;

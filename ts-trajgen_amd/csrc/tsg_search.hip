@@ -4,9 +4,6 @@
 
 #include "tsg_engine_dev.h"
 
-#ifndef TSG_ABLATE
-#define TSG_ABLATE 0  // timing-only ablation builds (tools/build_variant.sh); 0 in the shipped library
-#endif
 
 // =====================================================================================
 // explicit-row scoring: GeneratorV4.predict (generator_v4.py:56-72) for (prefix, candidates, dis) rows
@@ -128,6 +125,9 @@ extern "C" int tsg_geodesic_pairs(const double* geo, int32_t n_rows, int32_t n, 
 #ifndef TSG_SCORE_WPB
 #define TSG_SCORE_WPB 1
 #endif
+#ifndef TSG_SCORE_GROUP
+#define TSG_SCORE_GROUP 4  // key rows per group of the scoring kernel's attention loop; two groups are in flight (groups of 8: 143 us per launch against 117)
+#endif
 
 // =====================================================================================
 // engine scoring: one wave per work item of the current superstep
@@ -193,33 +193,29 @@ __global__ __launch_bounds__(256) void score_frontier_kernel(tsg_model m, Engine
     // lane t: the ancestor at distance t of `anchor` (lane 0 = the anchor itself)
     const int up1 = __shfl_up(list, 1, TSG_WAVE);
     const int cur = lane == 0 ? anchor : up1;
-    // groups of 4 rows, software-pipelined: group g+1 is loading while group g is folded
-    float keyA[4][JT], keyB[4][JT];
+    // groups of TSG_SCORE_GROUP rows, software-pipelined: group g+1 is loading while group g is folded
+    constexpr int G = TSG_SCORE_GROUP;
+    float keyA[G][JT], keyB[G][JT];
     unsigned presA = 0, presB = 0;
-    auto issue = [&](int i, float key[4][JT], unsigned& pres) {
-      const float* rows[4];
+    auto issue = [&](int i, float key[G][JT], unsigned& pres) {
+      const float* rows[G];
       pres = 0;
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < G; ++u) {
         const int src_lane = i + u < n ? i + u : n - 1;
         const int id = __shfl(cur, src_lane, TSG_WAVE);
         rows[u] = (i + u < n) ? htop + (size_t)id * hp : nullptr;
         if (rows[u]) pres |= 1u << u;
       }
-      attn_load4<JT>(key, rows, J, lane);
+      attn_load_n<JT, G>(key, rows, J, lane);
     };
     issue(0, keyA, presA);
-    for (int i = 0; i < n; i += 8) {
-      if (i + 4 < n) issue(i + 4, keyB, presB);
-#if TSG_ABLATE == 2
-      if (i == 0)
-#endif
-      attn_fold4<JT, SPLIT>(acc, keyA, presA, q);
-      if (i + 4 < n) {
-        if (i + 8 < n) issue(i + 8, keyA, presA);
-#if TSG_ABLATE != 2
-        attn_fold4<JT, SPLIT>(acc, keyB, presB, q);
-#endif
+    for (int i = 0; i < n; i += 2 * G) {
+      if (i + G < n) issue(i + G, keyB, presB);
+      attn_fold_n<JT, G, SPLIT>(acc, keyA, presA, q);
+      if (i + G < n) {
+        if (i + 2 * G < n) issue(i + 2 * G, keyA, presA);
+        attn_fold_n<JT, G, SPLIT>(acc, keyB, presB, q);
       }
     }
     if (base + 64 < depth) {  // next chunk: hop 64 up, fetch that slot's list
@@ -237,11 +233,7 @@ __global__ __launch_bounds__(256) void score_frontier_kernel(tsg_model m, Engine
     my_cand = D.e.cand_id[(size_t)b * D.g.max_degree + lane];  // the successor list the frontier kernel left
     my_dis = D.e.cand_lp[(size_t)b * D.g.max_degree + lane];   // written by cand_dis_kernel
   }
-#if TSG_ABLATE == 3
-  const float f = 1.0f / ncand + pooled[0] * 1e-9f + my_dis * 1e-9f;
-#else
   const float f = score_row<JT>(m, pooled, J, lane, ncand, my_cand, my_dis, des, nullptr, nullptr);
-#endif
   if (lane < ncand) D.e.cand_lp[(size_t)b * D.g.max_degree + lane] = logf(f) + lp_parent;  // search.py:370-373
 }
 
