@@ -120,6 +120,68 @@ int tsg_gat_forward(const tsg_gat_desc* d, void* stream);
 #define TSG_GAT_STATIC_SCRATCH_BYTES (8u << 20)
 int tsg_gat_forward_static(const tsg_gat_desc* d, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * GAT layer in TRAINING mode (row f4 of the scope table): GATLayerImp3.forward with live dropout
+ * (generator/gat.py:149,155,180) and its backward, as DistanceGatFC.forward / calculate_loss run them
+ * (generator/distance_gat_fc.py:44-95) and train_gan.py:284 re-encodes after every optimiser step.
+ * The dropouts are caller-supplied masks, already scaled by 1 / (1 - p) (NULL = no dropout), so a run is
+ * reproducible from the caller's seed and comparable with the reference's autograd under the same masks.
+ * tsg_gat_train_forward: x_d = x * m_in; p_d = (x_d . W^T) * m_proj; scores, edge softmax with the global max,
+ * att_d = att * m_att; aggregation + skip + head mean / concat + bias + ELU -> out.  Keeps x_d, p_d, s_src, s_trg,
+ * att, att_d for the backward.
+ * tsg_gat_train_backward: from d_out, the gradients of the sparse part: d_o (gradient of the per-head sums, also the
+ * gradient of the skip projection's output), d_p (gradient of the projection x_d . W^T), d_a_src, d_a_trg, d_bias.
+ * The dense products that remain (d_W = d_p^T . x_d, d_x_d = d_p . W, and the same for the skip projection) are
+ * tsg_gemm_f32 calls of the caller (ts-trajgen_amd/generator/gat.py).  Gradient through the global max
+ * (gat.py:221) is dropped: it is O(1e-16 / neighbourhood sum) of the attention gradients.
+ * Edge "slots" j are the edges sorted stably by target (in_ptr / in_src as in tsg_gat_desc); m_att, att, att_d and
+ * d_pre are indexed by slot.  out_ptr / out_slot list, per SOURCE node, the slots of its outgoing edges;
+ * slot_trg[j] is the target of slot j.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct tsg_gat_train {
+  int32_t n_nodes, n_edges, fin, heads, fout, concat, skip_identity, reserved;
+  const int32_t* in_ptr;   /* [N+1] */
+  const int32_t* in_src;   /* [E] */
+  const int32_t* out_ptr;  /* [N+1] (backward) */
+  const int32_t* out_slot; /* [E]   (backward) */
+  const int32_t* slot_trg; /* [E]   (backward) */
+  const float* x;          /* [N][FIN] */
+  const float* m_in;       /* [N][FIN] or NULL */
+  const float* m_proj;     /* [N][NH*F] or NULL */
+  const float* m_att;      /* [E][NH] by slot, or NULL */
+  const float* w_proj_t;   /* [FIN][NH*F] linear_proj.weight^T */
+  const float* w_skip_t;   /* [FIN][NH*F] skip_proj.weight^T (unused when skip_identity) */
+  const float* a_src;      /* [NH][F] */
+  const float* a_trg;      /* [NH][F] */
+  const float* bias;       /* [F] or [NH*F] (concat), or NULL */
+  float* x_d;              /* [N][FIN]   saved: x * m_in */
+  float* p_d;              /* [N][NH*F]  saved: projection after its dropout */
+  float* skip;             /* [N][NH*F]  workspace: x_d . Ws^T (unused when skip_identity) */
+  float* s_src;            /* [N][NH]    saved */
+  float* s_trg;            /* [N][NH]    saved */
+  float* att;              /* [E][NH]    saved: attention before its dropout */
+  float* att_d;            /* [E][NH]    saved: after */
+  float* gmax;             /* [1] */
+  float* out;              /* [N][F] or [N][NH*F] */
+  const float* d_out;      /* backward in: gradient of out */
+  float* d_o;              /* [N][NH*F] out: gradient of the per-head sums (= of the skip projection's output) */
+  float* d_p;              /* [N][NH*F] out: gradient of x_d . W^T */
+  float* d_pre;            /* [E][NH]   workspace */
+  float* ds_src;           /* [N][NH]   workspace */
+  float* ds_trg;           /* [N][NH]   workspace */
+  float* d_a_src;          /* [NH][F] out */
+  float* d_a_trg;          /* [NH][F] out */
+  float* d_bias;           /* like bias, out (NULL when bias is NULL) */
+  size_t in_bytes;         /* of x_d */
+  size_t node_feat_bytes;  /* of EACH of p_d, skip, d_o, d_p */
+  size_t score_bytes;      /* of EACH of s_src, s_trg, ds_src, ds_trg */
+  size_t edge_bytes;       /* of EACH of att, att_d, d_pre */
+  size_t out_bytes;        /* of out */
+} tsg_gat_train;
+
+int tsg_gat_train_forward(const tsg_gat_train* d, void* stream);
+int tsg_gat_train_backward(const tsg_gat_train* d, void* stream);
+
 /* GAT input features: x[n] = [lon_embed[nf[n][-2]], lat_embed[nf[n][-1]], nf[n][:-2]]
  * (generator/distance_gat_fc.py:191-197).  node_features [N][fraw] f32 (last two columns hold the
  * integer lon/lat grid cells), lon_embed [n_lon][gps], lat_embed [n_lat][gps], x [N][2*gps + fraw - 2].

@@ -11,14 +11,21 @@ import torch.nn.functional as F
 
 
 def gat_forward(x, edge_index, linear_proj_w, skip_proj_w, scoring_src, scoring_trg, bias,
-                num_heads, out_features, concat=False):
-    """generator/gat.py:138-200 (GATLayerImp3.forward) + :84-114 (skip_concat_bias), eval mode.
+                num_heads, out_features, concat=False, masks=None):
+    """generator/gat.py:138-200 (GATLayerImp3.forward) + :84-114 (skip_concat_bias).
 
-    x (N, FIN) f32, edge_index (2, E) int64 with row 0 = source, row 1 = target.
+    x (N, FIN) f32, edge_index (2, E) int64 with row 0 = source, row 1 = target.  Eval mode by default; with
+    `masks` = (m_in (N, FIN), m_proj (N, NH, F), m_att (E, NH)), each already scaled by 1 / (1 - p), the three
+    dropouts of training mode (gat.py:149, :155, :180) multiply by them: every op is a differentiable torch op, so
+    autograd through this function is the training-mode backward.
     """
     n = x.shape[0]
     nh, fo = num_heads, out_features
+    if masks is not None:
+        x = x * masks[0]                                                     # gat.py:149
     proj = F.linear(x, linear_proj_w).view(-1, nh, fo)                       # gat.py:153
+    if masks is not None:
+        proj = proj * masks[1].view(-1, nh, fo)                              # gat.py:155
     s_src = (proj * scoring_src).sum(dim=-1)                                 # gat.py:164
     s_trg = (proj * scoring_trg).sum(dim=-1)                                 # gat.py:165
     src, trg = edge_index[0], edge_index[1]
@@ -31,6 +38,8 @@ def gat_forward(x, edge_index, linear_proj_w, skip_proj_w, scoring_src, scoring_
     denom = torch.zeros((n, nh), dtype=ex.dtype)
     denom.scatter_add_(0, trg.unsqueeze(-1).expand_as(ex), ex)               # gat.py:246
     att = ex / (denom.index_select(0, trg) + 1e-16)                          # gat.py:251,230
+    if masks is not None:
+        att = att * masks[2]                                                 # gat.py:180
     weighted = proj_lift * att.unsqueeze(-1)                                 # gat.py:188
     out = torch.zeros((n, nh, fo), dtype=x.dtype)
     out.scatter_add_(0, trg.view(-1, 1, 1).expand_as(weighted), weighted)    # gat.py:263

@@ -59,6 +59,67 @@ def test_g1_gat_layer(case):
     np.testing.assert_allclose(out.cpu().numpy(), z['%s_out' % case], rtol=RTOL, atol=1e-5)
 
 
+GAT_PARAMS = ('linear_proj.weight', 'skip_proj.weight', 'scoring_fn_source', 'scoring_fn_target', 'bias')
+
+
+@pytest.mark.parametrize('case', ['a', 'b', 'c'])
+def test_g12_gat_layer_training(case):
+    """GATLayerImp3 in training mode on the HIP kernels (tsg_gat_train_forward / _backward through autograd) against
+    the reference's output and autograd gradients under the same recorded dropout masks (golden G12)."""
+    from ts_trajgen_amd.generator import GATLayerImp3
+    z = load_npz('g12_gat_train.npz')
+    nh, fo = z['%s_scoring_fn_source' % case].shape[1:]
+    fin = z['%s_x' % case].shape[1]
+    layer = GATLayerImp3(fin, fo, nh, DEV, concat=bool(z['%s_concat' % case]))
+    layer.load_state_dict({k: torch.as_tensor(z['%s_%s' % (case, k)]) for k in GAT_PARAMS})
+    layer = layer.to(DEV).train(True)
+    layer.dropout_masks = tuple(torch.as_tensor(z['%s_mask%d' % (case, i)]) for i in range(3))
+    x = torch.as_tensor(z['%s_x' % case]).to(DEV).requires_grad_(True)
+    out, _ = layer((x, torch.as_tensor(z['edge_index']).to(DEV)))
+    np.testing.assert_allclose(out.detach().cpu().numpy(), z['%s_out' % case], rtol=RTOL, atol=1e-5)
+    (out * torch.as_tensor(z['%s_up' % case]).to(DEV)).sum().backward()
+
+    def close(got, want, what):
+        scale = max(1e-6, float(np.abs(want).max()))
+        np.testing.assert_allclose(got, want, rtol=RTOL, atol=2e-5 * scale, err_msg=what)
+    close(x.grad.cpu().numpy(), z['%s_grad_x' % case], 'x')
+    for k in GAT_PARAMS:
+        p = dict(layer.named_parameters())[k]
+        g = p.grad.cpu().numpy() if p.grad is not None else np.zeros(tuple(p.shape), np.float32)
+        close(g, z['%s_grad_%s' % (case, k)], k)
+    # inference mode still runs the inference kernels and ignores the masks
+    layer.train(False)
+    z1 = load_npz('g1_gat.npz')
+    out1, _ = layer((torch.as_tensor(z1['%s_x' % case]).to(DEV), torch.as_tensor(z1['edge_index']).to(DEV)))
+    np.testing.assert_allclose(out1.cpu().numpy(), z1['%s_out' % case], rtol=RTOL, atol=1e-5)
+
+
+def test_g13_function_h_training_loss(road):
+    """DistanceGatFC.calculate_loss in training mode and the gradient of every parameter of function H against the
+    reference's (golden G13); then one optimiser step and update_node_emb (train_gan.py:284) run end to end."""
+    z = load_npz('g13_h_train.npz')
+    model = build_generator(road, DEV)
+    h = model.function_h
+    h.train(True)
+    h.gat_encoder.dropout_masks = tuple(torch.as_tensor(z['mask%d' % i]) for i in range(3))
+    cand, des, dis = (torch.as_tensor(z[k]).to(DEV) for k in ('cand', 'des', 'dis'))
+    h.zero_grad()
+    loss = h.calculate_loss(cand, des, dis, torch.as_tensor(z['target']).to(DEV))
+    assert abs(float(loss.detach()) - float(z["loss"])) <= RTOL * max(1.0, abs(float(z["loss"])))
+    loss.backward()
+    for k, p in h.named_parameters():
+        want = z['grad_' + k]
+        g = p.grad.cpu().numpy() if p.grad is not None else np.zeros(tuple(p.shape), np.float32)
+        scale = max(1e-6, float(np.abs(want).max()))
+        np.testing.assert_allclose(g, want, rtol=RTOL, atol=2e-5 * scale + 1e-7, err_msg=k)
+    before = h.gat_encoder.linear_proj.weight.detach().clone()
+    torch.optim.SGD(h.parameters(), lr=1e-3).step()
+    assert not torch.equal(before, h.gat_encoder.linear_proj.weight.detach())
+    h.train(False)
+    h.update_node_emb()
+    assert bool(torch.isfinite(h.node_emb_feature).all())
+
+
 def test_g2_node_embedding(road, road_model, region):
     road_model.function_h.node_emb_feature = None
     road_model.function_h._setup_node_emb()

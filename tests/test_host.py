@@ -44,7 +44,7 @@ def test_struct_sizes_match_header(tmp_path):
     """The ctypes mirrors are as large as the C structs of include/tsg.h (compiled here with gcc)."""
     import subprocess
     from ts_trajgen_amd import _lib
-    names = [('tsg_gat_desc', _lib.GatDesc), ('tsg_model', _lib.Model), ('tsg_lstm_step', _lib.LstmStep),
+    names = [('tsg_gat_desc', _lib.GatDesc), ('tsg_gat_train', _lib.GatTrain), ('tsg_model', _lib.Model), ('tsg_lstm_step', _lib.LstmStep),
              ('tsg_score_batch', _lib.ScoreBatch), ('tsg_graph', _lib.Graph), ('tsg_od_batch', _lib.OdBatch),
              ('tsg_engine', _lib.Engine), ('tsg_rollout', _lib.Rollout)]
     src = tmp_path / 'sizes.c'

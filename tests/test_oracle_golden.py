@@ -32,6 +32,50 @@ def test_g1_gat_layer(case):
     np.testing.assert_allclose(out.numpy(), z['%s_out' % case], rtol=RTOL, atol=1e-6)
 
 
+PARAMS = ('linear_proj.weight', 'skip_proj.weight', 'scoring_fn_source', 'scoring_fn_target', 'bias')
+
+
+@pytest.mark.parametrize('case', ['a', 'b', 'c'])
+def test_g12_gat_layer_training(case):
+    """Training mode: the reference layer under recorded dropout masks, its output and its autograd gradients."""
+    z = load_npz('g12_gat_train.npz')
+    t = lambda k: torch.as_tensor(z['%s_%s' % (case, k)])
+    nh, fo = z['%s_scoring_fn_source' % case].shape[1:]
+    x = t('x').clone().requires_grad_(True)
+    par = {k: t(k).clone().requires_grad_(True) for k in PARAMS}
+    out = om.gat_forward(x, torch.as_tensor(z['edge_index']), par['linear_proj.weight'], par['skip_proj.weight'],
+                         par['scoring_fn_source'], par['scoring_fn_target'], par['bias'], nh, fo,
+                         concat=bool(z['%s_concat' % case]), masks=(t('mask0'), t('mask1'), t('mask2')))
+    np.testing.assert_allclose(out.detach().numpy(), z['%s_out' % case], rtol=RTOL, atol=1e-6)
+    (out * t('up')).sum().backward()
+    np.testing.assert_allclose(x.grad.numpy(), z['%s_grad_x' % case], rtol=1e-4, atol=1e-5)
+    for k in PARAMS:
+        g = par[k].grad if par[k].grad is not None else torch.zeros_like(par[k])
+        np.testing.assert_allclose(g.numpy(), z['%s_grad_%s' % (case, k)], rtol=1e-4, atol=1e-5, err_msg=k)
+
+
+def test_g13_function_h_training_loss(road):
+    """DistanceGatFC.calculate_loss in training mode (distance_gat_fc.py:75-95) and every parameter's gradient."""
+    z = load_npz('g13_h_train.npz')
+    sd = {k: torch.as_tensor(v).clone().requires_grad_(True) for k, v in road.h_state.items()}
+    fh = road.cfg['function_h']
+    x = om.h_input_features(sd, torch.as_tensor(road.node_features), fh.get('no_gps_emb', False))
+    emb = om.gat_forward(x, torch.as_tensor(road.edge_index), sd['gat_encoder.linear_proj.weight'],
+                         sd['gat_encoder.skip_proj.weight'], sd['gat_encoder.scoring_fn_source'],
+                         sd['gat_encoder.scoring_fn_target'], sd['gat_encoder.bias'], fh['num_of_heads'],
+                         fh['embed_dim'], fh['concat'],
+                         masks=tuple(torch.as_tensor(z['mask%d' % i]) for i in range(3)))
+    cand, des, dis = torch.as_tensor(z['cand']), torch.as_tensor(z['des']), torch.as_tensor(z['dis'])
+    score = torch.stack([om.h_scores(sd, emb, cand[b], int(des[b]), dis[b]) for b in range(cand.shape[0])])
+    loss = torch.nn.functional.cross_entropy(score, torch.as_tensor(z['target']))
+    assert abs(float(loss.detach()) - float(z["loss"])) <= 1e-5 * max(1.0, abs(float(z["loss"])))
+    loss.backward()
+    for k, v in sd.items():
+        g = v.grad if v.grad is not None else torch.zeros_like(v)
+        scale = max(1e-6, float(np.abs(z['grad_' + k]).max()))
+        np.testing.assert_allclose(g.numpy(), z['grad_' + k], rtol=1e-4, atol=1e-5 * scale + 1e-7, err_msg=k)
+
+
 def test_g2_node_embedding(road, region):
     np.testing.assert_allclose(road.oracle_model().setup_node_emb().numpy(), road.npz['node_emb'],
                                rtol=RTOL, atol=1e-6)

@@ -6,7 +6,7 @@ name=$1; flags=$2
 src=ts-trajgen_amd/csrc
 obj=/tmp/tsg_variant_$name
 mkdir -p $obj ablate
-for f in tsg_dense tsg_search tsg_gat tsg_rollout; do
+for f in tsg_dense tsg_search tsg_gat tsg_gat_train tsg_rollout; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function $flags -c $src/$f.hip -o $obj/$f.o &
 done
 wait

@@ -77,6 +77,92 @@ def gen_g1():
     print('G1 done')
 
 
+# ----------------------------------------------------------------------------- G12: GAT layer, training mode
+class _MaskSeq(object):
+    """Stands in for the layer's nn.Dropout (gat.py:63): the k-th call multiplies by the k-th recorded mask."""
+
+    def __init__(self, masks):
+        self.masks, self.i = masks, 0
+
+    def __call__(self, t):
+        m = self.masks[self.i]
+        self.i += 1
+        return t * m.view(t.shape)
+
+
+def _set_dropout(layer, masks):
+    layer._modules.pop('dropout', None)
+    object.__setattr__(layer, 'dropout', _MaskSeq(masks))
+
+
+def gen_g12():
+    """The reference layer in training mode with RECORDED dropout masks (p = 0.6, kept entries scaled by 2.5) in
+    place of its nn.Dropout draws, and the gradients its autograd returns for loss = sum(out * G)."""
+    z = np.load(os.path.join(OUT, 'g1_gat.npz'))
+    edge_index = z['edge_index']
+    e = edge_index.shape[1]
+    out = {'edge_index': edge_index}
+    for name, fin, fout, concat in (('a', 20, 32, False), ('b', 32, 32, False), ('c', 12, 16, True)):
+        torch.manual_seed(100 + fin)
+        layer = GATLayerImp3(num_in_features=fin, num_out_features=fout, num_of_heads=5, device='cpu', concat=concat)
+        with torch.no_grad():
+            layer.bias.normal_(0, 0.1)
+        layer.train(True)
+        n = z['%s_x' % name].shape[0]
+        g = torch.Generator().manual_seed(500 + fin)
+        keep = 0.4
+        masks = [(torch.rand(s, generator=g) < keep).float() / keep for s in ((n, fin), (n, 5 * fout), (e, 5))]
+        _set_dropout(layer, masks)
+        x = torch.tensor(z['%s_x' % name], requires_grad=True)
+        y, _ = layer((x, torch.from_numpy(edge_index)))
+        up = torch.randn(y.shape, generator=g)
+        (y * up).sum().backward()
+        out['%s_x' % name] = x.detach().numpy()
+        out['%s_out' % name] = y.detach().numpy()
+        out['%s_up' % name] = up.numpy()
+        out['%s_concat' % name] = np.array(int(concat))
+        for i, m in enumerate(masks):
+            out['%s_mask%d' % (name, i)] = m.numpy()
+        out['%s_grad_x' % name] = x.grad.numpy()
+        for k, v in layer.named_parameters():
+            out['%s_%s' % (name, k)] = v.detach().numpy()
+            out['%s_grad_%s' % (name, k)] = (v.grad if v.grad is not None else torch.zeros_like(v)).numpy()
+    np.savez_compressed(os.path.join(OUT, 'g12_gat_train.npz'), **out)
+    print('G12 done')
+
+
+def gen_g13(net, model):
+    """DistanceGatFC.calculate_loss (distance_gat_fc.py:75-95) in training mode, the GAT's dropouts replaced by
+    recorded masks: the loss and the gradient of every parameter of function H."""
+    h = model.function_h
+    h.train(True)
+    n = h.node_features.shape[0]
+    e = h.Apt.shape[1]
+    g = torch.Generator().manual_seed(77)
+    keep = 0.4
+    nh, fo = h.num_of_heads, h.embed_dim
+    masks = [(torch.rand(s, generator=g) < keep).float() / keep for s in ((n, h.feature_dim), (n, nh * fo), (e, nh))]
+    _set_dropout(h.gat_encoder, masks)
+    rng = np.random.RandomState(5)
+    b, c = 24, 4
+    cand = torch.from_numpy(rng.randint(0, net.num_roads, size=(b, c)).astype(np.int64))
+    des = torch.from_numpy(rng.randint(0, net.num_roads, size=b).astype(np.int64))
+    dis = torch.from_numpy(rng.uniform(0.0, 60.0, size=(b, c)).astype(np.float32))
+    target = torch.from_numpy(rng.randint(0, c, size=b).astype(np.int64))
+    h.zero_grad()
+    loss = h.calculate_loss(cand, des, dis, target)
+    loss.backward()
+    out = {'cand': cand.numpy(), 'des': des.numpy(), 'dis': dis.numpy(), 'target': target.numpy(),
+           'loss': np.array(float(loss))}
+    for i, m in enumerate(masks):
+        out['mask%d' % i] = m.numpy()
+    for k, v in h.named_parameters():
+        out['grad_' + k] = (v.grad if v.grad is not None else torch.zeros_like(v)).numpy()
+    np.savez_compressed(os.path.join(OUT, 'g13_h_train.npz'), **out)
+    h.zero_grad()
+    print('G13 done, loss %.6f' % float(loss))
+
+
 # ----------------------------------------------------------------------------- shared small world
 ROAD_CFG = {
     'function_g': {'road_emb_size': 32, 'time_emb_size': 8, 'hidden_size': 32, 'dropout_p': 0.6,
@@ -578,6 +664,11 @@ def gen_bj_dims_config0(workers=6):
 
 if __name__ == '__main__':
     only = sys.argv[1] if len(sys.argv) > 1 else 'all'
+    if only == 'g12':                     # adds G12 / G13 next to the existing files (same deterministic world)
+        gen_g12()
+        net = messy_network()
+        gen_g13(net, build_road_model(net))
+        sys.exit(0)
     if only == 'g10':                     # adds G10 next to the existing files (same deterministic world)
         net = messy_network()
         gen_masked_batch(net, build_road_model(net))

@@ -15,7 +15,7 @@ TSG_H_HIDDEN = 10
 STATUS_UNTOUCHED, STATUS_REACHED, STATUS_FALLBACK, STATUS_OVERFLOW = 0, 1, 2, 0x100
 GAT_STATIC_SCRATCH_BYTES = 8 << 20     # TSG_GAT_STATIC_SCRATCH_BYTES
 
-EXPORTS = ('tsg_version', 'tsg_gemm_f32', 'tsg_gat_forward', 'tsg_gat_forward_static', 'tsg_gat_build_input', 'tsg_lstm_step_batched',
+EXPORTS = ('tsg_version', 'tsg_gemm_f32', 'tsg_gat_forward', 'tsg_gat_forward_static', 'tsg_gat_train_forward', 'tsg_gat_train_backward', 'tsg_gat_build_input', 'tsg_lstm_step_batched',
            'tsg_score_candidates', 'tsg_engine_reset', 'tsg_engine_run', 'tsg_engine_run_profiled', 'tsg_engine_graph_create', 'tsg_engine_graph_launch',
            'tsg_engine_graph_destroy', 'tsg_frontier_expand_select',
            'tsg_score_frontier', 'tsg_rollout_run', 'tsg_reconstruct_paths', 'tsg_h_pair_scores', 'tsg_geodesic_pairs')
@@ -33,6 +33,19 @@ class GatDesc(C.Structure):
                 ('out', _p), ('proj_bytes', _sz), ('s_bytes', _sz), ('out_bytes', _sz),
                 ('skip', _p), ('w_skip_mean', _p), ('skip_bytes', _sz), ('w_skip_mean_bytes', _sz),
                 ('w_att', _p), ('w_att_bytes', _sz)]
+
+
+class GatTrain(C.Structure):
+    _fields_ = [('n_nodes', _i32), ('n_edges', _i32), ('fin', _i32), ('heads', _i32), ('fout', _i32),
+                ('concat', _i32), ('skip_identity', _i32), ('reserved', _i32),
+                ('in_ptr', _p), ('in_src', _p), ('out_ptr', _p), ('out_slot', _p), ('slot_trg', _p),
+                ('x', _p), ('m_in', _p), ('m_proj', _p), ('m_att', _p), ('w_proj_t', _p), ('w_skip_t', _p),
+                ('a_src', _p), ('a_trg', _p), ('bias', _p),
+                ('x_d', _p), ('p_d', _p), ('skip', _p), ('s_src', _p), ('s_trg', _p), ('att', _p), ('att_d', _p),
+                ('gmax', _p), ('out', _p), ('d_out', _p), ('d_o', _p), ('d_p', _p), ('d_pre', _p), ('ds_src', _p),
+                ('ds_trg', _p), ('d_a_src', _p), ('d_a_trg', _p), ('d_bias', _p),
+                ('in_bytes', _sz), ('node_feat_bytes', _sz), ('score_bytes', _sz), ('edge_bytes', _sz),
+                ('out_bytes', _sz)]
 
 
 class Model(C.Structure):
@@ -112,6 +125,8 @@ def lib():
     L.tsg_gemm_f32.argtypes = [_p, C.c_int, _p, C.c_int, _p, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p]
     L.tsg_gat_forward.argtypes = [C.POINTER(GatDesc), _p]
     L.tsg_gat_forward_static.argtypes = [C.POINTER(GatDesc), _p]
+    L.tsg_gat_train_forward.argtypes = [C.POINTER(GatTrain), _p]
+    L.tsg_gat_train_backward.argtypes = [C.POINTER(GatTrain), _p]
     L.tsg_gat_build_input.argtypes = [_p, C.c_int, C.c_int, _p, C.c_int, _p, C.c_int, C.c_int, _p, _p]
     L.tsg_lstm_step_batched.argtypes = [C.POINTER(Model), C.POINTER(LstmStep), _p]
     L.tsg_score_candidates.argtypes = [C.POINTER(Model), C.POINTER(ScoreBatch), _p]

@@ -1,5 +1,6 @@
 """DistanceGatFC drop-in (function H; reference: generator/distance_gat_fc.py:9-42 constructor,
-:118-157 predict_cache/predict_next, :189-223 node-embedding cache).  Inference-only."""
+:118-157 predict_cache/predict_next, :189-223 node-embedding cache, :44-95 forward / calculate_loss in training
+mode)."""
 import ctypes as C
 
 import torch
@@ -34,6 +35,7 @@ class DistanceGatFC(nn.Module):
         self.emb_fc = nn.Linear(in_features=self.embed_dim * 2, out_features=10)
         self.dis_fc = nn.Linear(in_features=1, out_features=10)
         self.out_fc = nn.Linear(in_features=20, out_features=1)
+        self.loss_func = torch.nn.CrossEntropyLoss()
         self.node_emb_feature = None
 
     def _dev(self):
@@ -98,10 +100,37 @@ class DistanceGatFC(nn.Module):
     def forward(self, from_node, to_node, distance):
         """distance_gat_fc.py:44-74 for a module in inference mode: the reference re-encodes the graph on every call,
         which gives the cached embeddings again as long as the parameters have not changed (the device tables are
-        rebuilt when they have).  The training-mode forward (dropout 0.6 inside the GAT, autograd) is not built."""
+        rebuilt when they have).  In training mode: _forward_train (live dropout inside the GAT, differentiable)."""
         if self.training:
-            raise NotImplementedError('training forward/backward of function H is outside the generation path')
+            return self._forward_train(from_node, to_node, distance)
         return self._owner_tables('forward').h_pair_scores(from_node, to_node, distance)
+
+    def _forward_train(self, from_node, to_node, distance):
+        """distance_gat_fc.py:44-74 in training mode, differentiable: the graph is re-encoded by the GAT layer's
+        training kernels (live dropout, autograd node), the embedding look-ups and the 20-unit head around it are
+        torch ops on the device (a few thousand multiply-adds per batch)."""
+        dev = self._dev()
+        if dev.type != 'cuda':
+            raise RuntimeError('DistanceGatFC needs its parameters on a HIP device (no CPU fallback)')
+        nf = self.node_features.to(dev).float()
+        if not self.no_gps_emb:
+            in_feature = torch.cat([self.lon_embed(nf[:, -2].long()), self.lat_embed(nf[:, -1].long()), nf[:, :-2]],
+                                   dim=1)
+        else:
+            in_feature = nf
+        encode_feature = self.gat_encoder((in_feature, self.Apt.to(dev)))[0]
+        from_node_emb = encode_feature[from_node.to(dev)]
+        to_node_emb = encode_feature[to_node.to(dev)]
+        emb_fc_out = torch.relu(self.emb_fc(torch.cat([from_node_emb, to_node_emb], dim=1)))
+        dis_fc_out = torch.relu(self.dis_fc(distance.to(dev).float().unsqueeze(1)))
+        return self.out_fc(torch.cat([emb_fc_out, dis_fc_out], dim=1)).squeeze(1)
+
+    def calculate_loss(self, candidate_set, des, candidate_distance, target):
+        """Cross entropy of the candidates' scores (distance_gat_fc.py:75-95); same arguments."""
+        c = candidate_set.shape[1]
+        score = self.forward(candidate_set.flatten(), des.unsqueeze(1).repeat(1, c).flatten(),
+                             candidate_distance.flatten())
+        return self.loss_func(score.reshape(candidate_set.shape[0], c), target.to(score.device))
 
     def predict(self, candidate_set, des, candidate_distance):
         """softmax over the candidates of forward() (distance_gat_fc.py:97-116)."""
