@@ -110,3 +110,32 @@ def test_ordered_draw_equals_randomstate_choice():
         for _ in range(2):
             assert np.array_equal(r1.choice(a, n, p=p, replace=False), ordered_draw(r2, a, p))
         assert r1.randint(1 << 30) == r2.randint(1 << 30)
+
+
+def test_border_orders_equal_randomstate_choice():
+    """The C host helper (libtsg_host.so) draws the border-road orders of many OD pairs at once: for every OD pair the
+    k-th order is what the k-th RandomState(seed).choice(..., replace=False, p=...) call of the reference returns
+    (search.py:897-902), element for element, for seeds up to 2^32 - 1 and lists of 1..300 roads."""
+    from ts_trajgen_amd.search import border_orders
+    rs = np.random.RandomState(1)
+    pairs_a, pairs_p = [], []
+    for t in range(60):
+        n = int(rs.choice([1, 2, 3, 7, 40, 300]))
+        pairs_a.append(rs.randint(0, 100000, size=n))
+        f = np.ones(n) if t % 3 == 0 else rs.randint(1, 50, size=n).astype(float)
+        pairs_p.append(f / np.sum(f))
+    pair_ptr = np.zeros(len(pairs_a) + 1, dtype=np.int64)
+    np.cumsum([len(a) for a in pairs_a], out=pair_ptr[1:])
+    seeds = np.concatenate([np.arange(200), [2 ** 32 - 1, 123456789, 2 ** 31]]).astype(np.int64)
+    legs = [rs.randint(0, len(pairs_a), size=int(rs.randint(0, 6))) for _ in seeds]
+    leg_ptr = np.zeros(len(seeds) + 1, dtype=np.int64)
+    np.cumsum([len(l) for l in legs], out=leg_ptr[1:])
+    out_ptr, out_idx = border_orders(seeds, leg_ptr, np.concatenate(legs).astype(np.int32), pair_ptr,
+                                     np.concatenate(pairs_p))
+    for i, sd in enumerate(seeds):
+        r = np.random.RandomState(int(sd))
+        for k, q in enumerate(legs[i]):
+            l = int(leg_ptr[i]) + k
+            want = r.choice(pairs_a[q], len(pairs_a[q]), p=pairs_p[q], replace=False)
+            got = pairs_a[q][out_idx[out_ptr[l]:out_ptr[l + 1]]]
+            assert np.array_equal(want, got), (i, k)

@@ -37,5 +37,6 @@ torch.cuda.synchronize()
 dt = time.time() - t0
 reached = sum(int(l[-1] == d) for l, d in zip(locs, od['des']))
 print('two-stage: %d OD pairs in %.2f s = %.0f trajectories/s; reached %d (%.1f%%); rounds %d; road expansions %d; '
-      'mean length %.1f' % (n_od, dt, n_od / dt, reached, 100.0 * reached / n_od, s.last_stats['rounds'],
-                            s.last_stats['road_expansions'], np.mean([len(l) for l in locs])))
+      'mean length %.1f; inside the engine calls %.0f%% of the wall time'
+      % (n_od, dt, n_od / dt, reached, 100.0 * reached / n_od, s.last_stats['rounds'],
+         s.last_stats['road_expansions'], np.mean([len(l) for l in locs]), 100.0 * s.last_stats['gpu_busy_frac']))

@@ -151,6 +151,23 @@ def lib():
     return L
 
 
+_host = None
+
+
+def host_lib():
+    """libtsg_host.so: the plain-C host helper (exact numpy RandomState draws for the two-stage search)."""
+    global _host
+    if _host is None:
+        path = os.path.join(_HERE, 'csrc', 'libtsg_host.so')
+        if not os.path.exists(path):
+            raise RuntimeError('libtsg_host.so is not built (%s): run `make -C ts-trajgen_amd/csrc`' % path)
+        H = C.CDLL(path)
+        H.tsg_host_border_orders.argtypes = [_i32, _p, _p, _p, _p, _p, _p, _p, _i32]
+        H.tsg_host_border_orders.restype = C.c_int
+        _host = H
+    return _host
+
+
 def check(rc, what):
     if rc != 0:
         names = {-1: 'TSG_E_INVALID', -2: 'TSG_E_TOO_SMALL', -3: 'TSG_E_LIMIT'}

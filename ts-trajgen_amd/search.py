@@ -4,6 +4,7 @@ Same constructor and `astar_search*` signatures and return values as the referen
 entry `generate(...)` that runs many OD pairs at once on the device engine (the reference loops them
 one at a time, our_model_generate.py:417-426).  All search state lives in HBM (csrc/tsg_search.hip).
 """
+import ctypes as C
 import json
 import os
 
@@ -211,6 +212,34 @@ def ordered_draw(rng, a, p):
     return a[found]
 
 
+def border_orders(seeds, leg_ptr, leg_pair, pair_ptr, pair_p):
+    """The border-road orders of many OD pairs at once (search.py:897-902): OD pair i draws, from its own
+    numpy.random.RandomState(seeds[i]), one order per leg leg_ptr[i] <= l < leg_ptr[i+1]; leg l permutes the list of
+    pair leg_pair[l], whose (normalised) probabilities are pair_p[pair_ptr[q]:pair_ptr[q+1]].  Returns (out_ptr,
+    out_idx): the order of leg l is out_idx[out_ptr[l]:out_ptr[l+1]] (indices into the pair's list), element for
+    element what ordered_draw / RandomState.choice(replace=False, p=...) return (tests/test_host.py).  Runs in
+    libtsg_host.so (plain C): seeding 10^5 generators and drawing in Python was the bottleneck of the two-stage path."""
+    H = _lib.host_lib()
+    seeds = np.ascontiguousarray(np.asarray(seeds, dtype=np.int64) & 0xFFFFFFFF, dtype=np.uint32)
+    leg_ptr = np.ascontiguousarray(leg_ptr, dtype=np.int64)
+    leg_pair = np.ascontiguousarray(leg_pair, dtype=np.int32)
+    pair_ptr = np.ascontiguousarray(pair_ptr, dtype=np.int64)
+    pair_p = np.ascontiguousarray(pair_p, dtype=np.float64)
+    sizes = (pair_ptr[1:] - pair_ptr[:-1])[leg_pair] if len(leg_pair) else np.zeros(0, dtype=np.int64)
+    out_ptr = np.zeros(len(leg_pair) + 1, dtype=np.int64)
+    np.cumsum(sizes, out=out_ptr[1:])
+    out_idx = np.zeros(max(1, int(out_ptr[-1])), dtype=np.int32)
+    max_size = int((pair_ptr[1:] - pair_ptr[:-1]).max()) if len(pair_ptr) > 1 else 1
+
+    def ptr(a):
+        return a.ctypes.data_as(C.c_void_p)
+    rc = H.tsg_host_border_orders(len(seeds), ptr(seeds), ptr(leg_ptr), ptr(leg_pair), ptr(pair_ptr), ptr(pair_p),
+                                  ptr(out_ptr), ptr(out_idx), max(1, max_size))
+    if rc != 0:
+        raise RuntimeError('tsg_host_border_orders failed (%d)' % rc)
+    return out_ptr, out_idx
+
+
 class DoubleLayerSearcher(object):
     """Two-stage search (reference: search.py:821-934): region-level A* first (search.py:936-1117), then
     road-level A* inside each region of the region path towards a border road drawn from the transfer
@@ -310,17 +339,22 @@ class DoubleLayerSearcher(object):
         """Returns (list of trace_loc, list of trace_tim, list of is_astar).
         leg_lmax: width of the output rows of a round of legs (default: 256 or more, by the longest prefix); legs
         whose trajectory is longer are run again with a wider row, so the value never changes a result."""
+        import time
         n = len(des_rids)
         if n == 0:          # e.g. a rank whose shard of the OD list is empty: nothing to run, still a valid result
             self.last_stats = {'rounds': 0, 'road_expansions': 0}
             return [], [], []
+        t_begin = time.time()
+        t_engine = 0.0      # wall time inside the batched engine calls (region search + road legs)
         ms = np.broadcast_to(np.asarray(max_step, dtype=np.int32), (n,)).copy()
         if rngs is None:
             rngs = [None] * n      # RandomState(seed of OD i), made when OD i first draws (seeding costs 25 us)
         self._label_roads()
         sreg = [self.rid2region[str(int(r))] for r in start_rids]
         dreg = [self.rid2region[str(int(r))] for r in des_rids]
+        t0 = time.time()
         region_traces, is_astar = self._region_paths(region_model, sreg, start_times, dreg, ms)
+        t_engine += time.time() - t0
         for i in range(n):
             if is_astar[i] != 1:
                 self.region_fail_find_log.add((sreg[i], dreg[i]))
@@ -346,6 +380,55 @@ class DoubleLayerSearcher(object):
         label_np = lab.cpu().numpy() if lab is not None else None
         pair_cache = {}
 
+        vector = all(r is None for r in rngs)    # every OD pair draws from RandomState(seed): orders pre-drawn in C
+        if vector:
+            # all legs of all OD pairs: region pair -> (border rids, probabilities); one order per leg, drawn up front
+            # (leg k of an OD pair takes the k-th draw of its generator whether or not the legs before it succeed)
+            pair_id, pair_rids, pair_ps = {}, [], []
+            leg_ptr = np.zeros(n + 1, dtype=np.int64)
+            np.cumsum(nleg, out=leg_ptr[1:])
+            leg_pair = np.zeros(int(leg_ptr[-1]), dtype=np.int32)
+            leg_from = np.zeros(int(leg_ptr[-1]), dtype=np.int32)
+            for i, rt in enumerate(region_traces):
+                o = int(leg_ptr[i])
+                for k in range(len(rt) - 1):
+                    key = (rt[k], rt[k + 1])
+                    q = pair_id.get(key)
+                    if q is None:
+                        b = self.region_transfer_freq[str(rt[k])][str(rt[k + 1])]
+                        freq = np.array(b['transfer_freq'])
+                        q = pair_id[key] = len(pair_rids)
+                        pair_rids.append(np.asarray(b['transfer_rid'], dtype=np.int32))
+                        pair_ps.append(freq / np.sum(freq))
+                    leg_pair[o + k] = q
+                    leg_from[o + k] = rt[k]
+            pair_ptr = np.zeros(len(pair_rids) + 1, dtype=np.int64)
+            np.cumsum([len(r) for r in pair_rids], out=pair_ptr[1:])
+            rid_cat = np.concatenate(pair_rids) if pair_rids else np.zeros(0, dtype=np.int32)
+            p_cat = np.concatenate(pair_ps) if pair_ps else np.zeros(0, dtype=np.float64)
+            sd = np.asarray(seeds, dtype=np.int64) if seeds is not None else np.arange(n, dtype=np.int64)
+            out_ptr, out_idx = border_orders(sd, leg_ptr, leg_pair, pair_ptr, p_cat)
+            order_rid = rid_cat[pair_ptr[leg_pair].repeat(np.diff(out_ptr)) + out_idx[:int(out_ptr[-1])]] \
+                if len(leg_pair) else np.zeros(0, dtype=np.int32)
+            last_reg = np.array([rt[-1] for rt in region_traces], dtype=np.int32)
+            in_last = (label_np[des_np] == last_reg) if label_np is not None else np.zeros(n, dtype=bool)
+
+        def set_targets(ids):
+            """target / allow / olen of the OD pairs `ids` from the pre-drawn orders (vector form of set_target)"""
+            if ids.size == 0:
+                return
+            il = leg[ids] < nleg[ids]
+            gl = np.minimum(leg_ptr[ids] + leg[ids], max(0, len(leg_pair) - 1))
+            if len(leg_pair):
+                olen[ids] = np.where(il, out_ptr[gl + 1] - out_ptr[gl], 0)
+                pos = np.minimum(out_ptr[gl] + np.minimum(attempt[ids], np.maximum(olen[ids] - 1, 0)),
+                                 max(0, len(order_rid) - 1))
+                target[ids] = np.where(il, order_rid[pos] if len(order_rid) else 0, des_np[ids])
+                allow[ids] = np.where(il, leg_from[gl], np.where(in_last[ids], last_reg[ids], -1))
+            else:
+                target[ids] = des_np[ids]
+                allow[ids] = np.where(in_last[ids], last_reg[ids], -1)
+
         def set_target(i):
             rt = region_traces[i]
             k = int(leg[i])
@@ -370,8 +453,11 @@ class DoubleLayerSearcher(object):
                 target[i] = des
                 allow[i] = int(rt[-1]) if in_last else -1                                  # search.py:925-931
 
-        for i in range(n):
-            set_target(i)
+        if vector:
+            set_targets(np.arange(n))
+        else:
+            for i in range(n):
+                set_target(i)
         while True:
             act = np.flatnonzero(~done)
             m = int(act.size)
@@ -384,9 +470,11 @@ class DoubleLayerSearcher(object):
             lmax = max(256, int(ln.max()) + 64, int(dl_np[act].max()) + 1)
             lmax = (lmax + 255) // 256 * 256 if leg_lmax is None else int(leg_lmax)
             tgt = target[act]
+            t0 = time.time()
             res = self.road_search.generate(road_model, None, None, tgt, dl_np[act], max_step=ms[act],
                                             prefixes=(ptr, p_rid[act][keep], p_tim[act][keep]), allow_label=allow[act],
                                             slots=slots, lmax=lmax)
+            t_engine += time.time() - t0
             expansions += self.road_search.last_stats.get('expansions', 0)
             rounds += 1
             r_rid, r_time = res['rid'].numpy(), res['time'].numpy()
@@ -430,8 +518,11 @@ class DoubleLayerSearcher(object):
             hit = last == tgt
             adv = act[in_leg & hit]                                      # search.py:912-914
             leg[adv] += 1
-            for i in adv.tolist():
-                order[i] = None
+            if vector:
+                attempt[adv] = 0
+            else:
+                for i in adv.tolist():
+                    order[i] = None
             miss = in_leg & ~hit
             if miss.any():
                 self.fail_find_log.update(zip(last[miss].tolist(), tgt[miss].tolist()))      # search.py:917
@@ -443,11 +534,17 @@ class DoubleLayerSearcher(object):
             if bad.any():
                 self.fail_find_log.update(zip(last[bad].tolist(), des_np[act][bad].tolist()))   # search.py:932-933
             done[act[fin]] = True
-            for i in act[~done[act]].tolist():
-                set_target(i)
+            if vector:
+                set_targets(act[~done[act]])
+            else:
+                for i in act[~done[act]].tolist():
+                    set_target(i)
         loc = [p_rid[i, :plen[i]].tolist() for i in range(n)]
         tim = [p_tim[i, :plen[i]].tolist() for i in range(n)]
-        self.last_stats = {'rounds': rounds, 'road_expansions': expansions}
+        # share of the wall time spent inside the engine calls (the device runs supersteps throughout them; the rest is
+        # the host between rounds: targets, prefixes, logs)
+        self.last_stats = {'rounds': rounds, 'road_expansions': expansions,
+                           'gpu_busy_frac': t_engine / max(1e-9, time.time() - t_begin)}
         return loc, tim, is_astar
 
     def astar_search(self, region_model, road_model, start_rid, start_tim, des, default_len, max_step=500):
