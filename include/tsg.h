@@ -318,7 +318,8 @@ typedef struct tsg_engine {
   int32_t slots;     /* B: searches in flight */
   int32_t exp_cap;   /* expanded nodes per slot  >= max prefix + max max_step */
   int32_t node_cap;  /* discovered nodes per slot (<= 2^20 - 1) */
-  int32_t heap_cap;  /* heap entries per slot */
+  int32_t heap_cap;  /* words of a slot's queue stretch: a multiple of 8, capacity heap_cap - 1 entries (entry i sits at
+                        word i + 1, which aligns the runs heappop reads to 64-byte sectors) */
   /* workspaces (caller-allocated); *_bytes are checked against the dims above */
   int32_t* slot_state;  size_t slot_state_bytes;  /* [B][40] int32 */
   uint64_t* heap;       size_t heap_bytes;        /* [B][heap_cap] {float prio; int32 node} */
@@ -386,7 +387,8 @@ typedef struct tsg_engine {
                                                      12 fewest free pages seen, 13 admission quota, 14 restart budget.
                                                      shared_counters: 2 next OD, 3 finished ODs, 4 total expansions,
                                                      6 error flag.  Per-slot statistics live in slot_state words
-                                                     27..29: model evaluations, scored candidates, attention rows */
+                                                     16..21: model evaluations, scored candidates, attention rows, work
+                                                     items, skipped expansions, waits for a page */
 } tsg_engine;
 
 /* Reset slot states, the rid table, the page ring and `counters` for a new OD batch (enqueues memsets and one

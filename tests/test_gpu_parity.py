@@ -238,9 +238,9 @@ def test_reconstruct_paths(road, road_model):
     eng = list(s._engines.values())[0]
     ss = eng.slot_state.cpu().numpy()
     em = eng.exp_meta.cpu().numpy()                      # [slots][exp_cap][parent, rid, tcode, depth]
-    used = [b for b in range(eng.slots) if ss[b, 6] == 1 and ss[b, 5] > 0]      # SS_GEN == 1, SS_EXP_N > 0
+    used = [b for b in range(eng.slots) if ss[b, 23] == 1 and ss[b, 4] > 0]     # SS_GEN == 1, SS_EXP_N > 0
     assert len(used) >= len(cases) - 4
-    node = [int(ss[b, 5]) - 1 for b in used]
+    node = [int(ss[b, 4]) - 1 for b in used]
     lmax = 64
     rid, tim, ln = eng.reconstruct_paths(used, node, lmax=lmax)
     rid2, tim2, ln2 = eng.reconstruct_paths(used + [10 ** 6], node + [0], last_rid=[7] * len(used) + [7],
@@ -255,7 +255,7 @@ def test_reconstruct_paths(road, road_model):
             cur = int(em[b, cur, 0])
         want_r, want_t = want_r[::-1], want_t[::-1]
         assert len(want_r) == int(em[b, nd, 3]) == ln[k]
-        od = int(ss[b, 1])                                  # SS_OD: the OD pair this slot ran
+        od = int(ss[b, 22])                                 # SS_OD: the OD pair this slot ran
         assert want_r[0] == cases[od]['start']
         n = min(len(want_r), lmax)
         assert rid[k, :n].tolist() == want_r[:n] and tim[k, :n].tolist() == want_t[:n]

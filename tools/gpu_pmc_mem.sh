@@ -6,8 +6,8 @@ export TMPDIR=/tmp
 mkdir -p gpurun_out
 B="bench.py --ods 32768 --warmup 0 --cpu-seconds 0 --profile-every 0 --two-stage-ods 0"
 rm -rf gpurun_out/${tag}_a gpurun_out/${tag}_b
-timeout -s KILL 300 rocprofv3 --pmc TCP_TCC_READ_REQ_LATENCY_sum TCP_TCC_READ_REQ_sum TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_REQUEST_sum --output-format csv -d gpurun_out/${tag}_a -- python3 $B > gpurun_out/${tag}_a.log 2>&1 || { tail -20 gpurun_out/${tag}_a.log; exit 1; }
-timeout -s KILL 300 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum --output-format csv -d gpurun_out/${tag}_b -- python3 $B > gpurun_out/${tag}_b.log 2>&1 || { tail -20 gpurun_out/${tag}_b.log; exit 1; }
+timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/${tag}_a -- python3 $B > gpurun_out/${tag}_a.log 2>&1 || { tail -20 gpurun_out/${tag}_a.log; exit 1; }
+timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/${tag}_b -- python3 $B > gpurun_out/${tag}_b.log 2>&1 || { tail -20 gpurun_out/${tag}_b.log; exit 1; }
 python3 - <<PY
 import csv, glob, collections
 for d in ('gpurun_out/${tag}_a', 'gpurun_out/${tag}_b'):

@@ -64,14 +64,23 @@ __device__ __forceinline__ float tsg_wave_max_u(float v) {
 __device__ __forceinline__ float tsg_sigmoid(float x) { return __frcp_rn(1.0f + __expf(-x)); }
 __device__ __forceinline__ float tsg_tanh(float x) { return 1.0f - 2.0f * __frcp_rn(1.0f + __expf(2.0f * x)); }
 
-// slot-state word indices (engine.slot_state is [B][SS_WORDS = 40] int32)
+// slot-state word indices (engine.slot_state is [B][SS_WORDS = 40] int32).  The words are grouped by how often they
+// change, and the frontier kernel writes a group back as whole 16-byte pieces (every store instruction of a lane is
+// a request of its own to the L2, and the frontier kernel is bound by its request count):
+//   words  0..7   change every superstep
+//   words  8..15  the expansion the search waits for (written when a node is expanded); once the search is over
+//                 (PH_FINISH) the same words hold its result: SS_FIN_* alias them
+//   words 16..19  per-slot statistics, summed on the host
+//   words 20..    set when a search starts (OD pair, prefix, fallback snapshot) or rarely
 enum {
-  SS_PHASE = 0, SS_OD, SS_STEP, SS_HEAP_N, SS_NODE_N, SS_EXP_N, SS_GEN, SS_WOFF, SS_DES, SS_DEFLEN,
-  SS_MAXSTEP, SS_ALLOW, SS_WARM_K, SS_PLEN, SS_CUR_EXP, SS_CUR_RID, SS_CUR_C, SS_CUR_DATE_TIME,
-  SS_CUR_LP, SS_BEST_LP, SS_BEST_PARENT, SS_BEST_RID, SS_BEST_TCODE, SS_HAVE_BEST, SS_NPOP, SS_POFF,
-  SS_CUR_DEPTH, SS_ST_EVALS, SS_ST_CAND, SS_ST_CHAIN, SS_CUR_COST, SS_ST_SKIPPED, SS_ST_ITEMS, SS_PAGES, SS_ST_STALLS,
+  SS_PHASE = 0, SS_STEP, SS_HEAP_N, SS_NODE_N, SS_EXP_N, SS_NPOP, SS_PAGES,
   SS_LAST_PAGE,  // the state page taken last (= the page of the next expansion's row once ensure_page succeeded)
-  SS_FIN_STATUS, SS_FIN_PARENT, SS_FIN_RID, SS_FIN_TCODE,  // PH_FINISH: the result (its length is parked in SS_CUR_DEPTH)
+  SS_CUR_EXP = 8, SS_CUR_RID, SS_CUR_C, SS_CUR_DATE_TIME, SS_CUR_COST, SS_CUR_LP, SS_CUR_DEPTH, SS_CUR_SPARE,
+  SS_FIN_STATUS = SS_CUR_EXP, SS_FIN_PARENT = SS_CUR_RID, SS_FIN_RID = SS_CUR_C, SS_FIN_TCODE = SS_CUR_DATE_TIME,
+  SS_FIN_DEPTH = SS_CUR_DEPTH,
+  SS_ST_EVALS = 16, SS_ST_CAND, SS_ST_CHAIN, SS_ST_ITEMS,
+  SS_ST_SKIPPED = 20, SS_ST_STALLS, SS_OD, SS_GEN, SS_WOFF, SS_DES, SS_DEFLEN, SS_MAXSTEP, SS_ALLOW, SS_WARM_K, SS_PLEN,
+  SS_POFF, SS_BEST_LP, SS_BEST_PARENT, SS_BEST_RID, SS_BEST_TCODE, SS_HAVE_BEST,
   SS_WORDS = 40
 };
 // PH_FINISH: the search is over and its result is parked in the slot (SS_FIN_*); the next superstep writes the

@@ -567,7 +567,11 @@ __global__ __launch_bounds__(256) void frontier_kernel(EngineDev D, int superste
   CKPT(0);  // first round trip
   int32_t itw[IT_WORDS] = {0};  // the work item of this superstep, if one is emitted: written to the work list at the end
   int32_t* shared = D.e.shared_counters;  // OD queue + completion, common to all sub-engines of a batch
-  uint64_t* heap = D.e.heap + (size_t)b * D.e.heap_cap;
+  // entry i of the queue sits at word i + 1 of the slot's stretch (whose length is a multiple of 8 entries): the
+  // runs heappop reads, 2 / 4 / 8 entries from 2p+1 / 4p+3 / 8p+7, are then 16- / 32- / 64-byte aligned and each
+  // lies in one 64-byte sector instead of straddling two
+  uint64_t* heap = D.e.heap + (size_t)b * D.e.heap_cap + 1;
+  const int heap_room = D.e.heap_cap - 1;
   uint64_t* table = D.e.table + (size_t)b * g.n_roads;
   int32_t* nodes = D.e.nodes + (size_t)b * D.e.node_cap * ND_WORDS;
   int32_t* em = D.e.exp_meta + (size_t)b * D.e.exp_cap * EM_WORDS;
@@ -581,7 +585,10 @@ __global__ __launch_bounds__(256) void frontier_kernel(EngineDev D, int superste
   const int cur_exp = sv[SS_CUR_EXP], cur_rid = sv[SS_CUR_RID], cur_c = sv[SS_CUR_C], cur_date_time = sv[SS_CUR_DATE_TIME];
   const int cur_cost = sv[SS_CUR_COST], cur_lp = sv[SS_CUR_LP], cur_depth = sv[SS_CUR_DEPTH];
   const float best_lp_in = __int_as_float(sv[SS_BEST_LP]);
-  int st_cand = 0, st_chain = 0, st_flags = 0;  // statistics of this superstep: bit 0 eval, 1 item, 2 stall, 8.. skipped
+  int st_evals = sv[SS_ST_EVALS], st_cand = sv[SS_ST_CAND], st_chain = sv[SS_ST_CHAIN], st_items = sv[SS_ST_ITEMS];
+  int st_flags = 0;  // rare statistics of this superstep: bit 2 stall, 8.. skipped expansions
+  int4 cur_new = make_int4(0, 0, 0, 0), cur_new2 = make_int4(0, 0, 0, 0);  // words 8..15 when they change
+  bool cur_dirty = false;
   int err = 0;
   // state pages (include/tsg.h, tsg_engine): this search's page list, the shared free ring, control words
   int pages_held = sv[SS_PAGES], last_page = sv[SS_LAST_PAGE];
@@ -688,7 +695,7 @@ __global__ __launch_bounds__(256) void frontier_kernel(EngineDev D, int superste
         bool pushed = false;
         int idx = -1;
         if ((int)(t >> TSG_GEN_SHIFT) != gen) {  // c not in rid2node and not in close_set
-          if (node_n >= D.e.node_cap || heap_n >= D.e.heap_cap) {
+          if (node_n >= D.e.node_cap || heap_n >= heap_room) {
             err = 1;
             continue;
           }
@@ -700,7 +707,7 @@ __global__ __launch_bounds__(256) void frontier_kernel(EngineDev D, int superste
         } else {
           idx = (int)(t & TSG_NODE_MASK);
           if (tlp < lp) {  // c in rid2node, strictly better
-            if (heap_n >= D.e.heap_cap) {
+            if (heap_n >= heap_room) {
               err = 1;
               continue;
             }
@@ -746,7 +753,7 @@ __global__ __launch_bounds__(256) void frontier_kernel(EngineDev D, int superste
   if (phase == PH_FINISH) {  // the search ended in the previous superstep: write its result, give the pages back
     int fin_status = sv[SS_FIN_STATUS];
     const int fin_parent = sv[SS_FIN_PARENT], fin_rid = sv[SS_FIN_RID], fin_tcode = sv[SS_FIN_TCODE];
-    const int fin_depth = sv[SS_CUR_DEPTH];
+    const int fin_depth = sv[SS_FIN_DEPTH];
     const int lmax = od.lmax;
     if (fin_depth > lmax) fin_status |= TSG_STATUS_OVERFLOW;
     const int parent_row =
@@ -867,7 +874,7 @@ __global__ __launch_bounds__(256) void frontier_kernel(EngineDev D, int superste
       it[IT_DEPTH] = k + 1;
       *reinterpret_cast<int2*>(D.e.row_meta + 2 * (size_t)it[IT_ROW]) = make_int2(it[IT_RID], it[IT_TCODE]);
       item_depth = k + 1;
-      st_flags |= 2;
+      st_items += 1;
       D.e.page_flags[(b & 255) * 32] = ss_stamp;
       if (k + 1 >= plen - 1) phase = PH_SEARCH;
       emitted = true;
@@ -990,22 +997,18 @@ __global__ __launch_bounds__(256) void frontier_kernel(EngineDev D, int superste
         for (int k = 0; k < 4; ++k)
           if (i0 + k < C) D.e.cand_id[(size_t)b * md + i0 + k] = s[k];
       }
-      S[SS_CUR_EXP] = e;
-      S[SS_CUR_RID] = rid;
-      S[SS_CUR_C] = C;
-      S[SS_CUR_DATE_TIME] = date_time;
-      S[SS_CUR_COST] = cost;
-      S[SS_CUR_LP] = nd_lp;
-      S[SS_CUR_DEPTH] = depth;
+      cur_new = make_int4(e, rid, C, date_time);
+      cur_new2 = make_int4(cost, nd_lp, depth, 0);
+      cur_dirty = true;
       if (C > 1) {  // per-slot statistics (summed on the host; no same-address atomics on the hot path)
-        st_flags |= 1;
-        st_cand = C;
-        st_chain = depth;
+        st_evals += 1;
+        st_cand += C;
+        st_chain += depth;
       }
       int32_t* it = itw;
       it[IT_SLOT] = b;
       it[IT_ROW] = last_page * TSG_PAGE_ROWS + (e & (TSG_PAGE_ROWS - 1));
-      st_flags |= 2;
+      st_items += 1;
       it[IT_PROW] = parent >= 0 ? ppage * TSG_PAGE_ROWS + (parent & (TSG_PAGE_ROWS - 1)) : -1;
       it[IT_RID] = rid;
       it[IT_TCODE] = tcode;
@@ -1040,11 +1043,9 @@ __global__ __launch_bounds__(256) void frontier_kernel(EngineDev D, int superste
         fin_depth = plen;
       }
     }
-    S[SS_FIN_STATUS] = fin_status;
-    S[SS_FIN_PARENT] = fin_parent;
-    S[SS_FIN_RID] = fin_rid;
-    S[SS_FIN_TCODE] = fin_tcode;
-    S[SS_CUR_DEPTH] = fin_depth;
+    cur_new = make_int4(fin_status, fin_parent, fin_rid, fin_tcode);  // SS_FIN_* (the words of the expansion waited for)
+    cur_new2 = make_int4(0, 0, fin_depth, 0);
+    cur_dirty = true;
     D.e.page_flags[(b & 255) * 32] = ss_stamp;
     phase = PH_FINISH;
     break;
@@ -1097,22 +1098,18 @@ __global__ __launch_bounds__(256) void frontier_kernel(EngineDev D, int superste
   st_acc[9] = clock64() - st_t0; st_acc[14] = 1; st_acc[15] = st_t0; st_acc[11] = wall_clock64();
   if (ss_now == TSG_STAMP_AT && b < 32768) for (int i = 0; i < 32; ++i) g_stamp[(size_t)b * 32 + i] = (unsigned long long)st_acc[i];
 #endif
-  // slot state back (the words kept in registers) and the statistics (per-slot words summed on the host: no
-  // same-address atomics on the hot path; nobody waits for these)
-  S[SS_PHASE] = phase;
-  S[SS_STEP] = step;
-  S[SS_HEAP_N] = heap_n;
-  S[SS_NODE_N] = node_n;
-  S[SS_EXP_N] = exp_n;
-  S[SS_NPOP] = npop;
-  S[SS_PAGES] = pages_held;
-  S[SS_LAST_PAGE] = last_page;
-  if (st_flags & 1) {
-    atomicAdd(&S[SS_ST_EVALS], 1);
-    atomicAdd(&S[SS_ST_CAND], st_cand);
-    atomicAdd(&S[SS_ST_CHAIN], st_chain);
+  // slot state back, in whole 16-byte pieces (tsg_common.h): the words of every superstep, the expansion waited for
+  // (or the result) when it changed, the statistics; the rare counters with atomics nobody waits for
+  {
+    int4* S4 = reinterpret_cast<int4*>(S);
+    S4[0] = make_int4(phase, step, heap_n, node_n);
+    S4[1] = make_int4(exp_n, npop, pages_held, last_page);
+    if (cur_dirty) {
+      S4[2] = cur_new;
+      S4[3] = cur_new2;
+    }
+    if (st_items != sv[SS_ST_ITEMS]) S4[4] = make_int4(st_evals, st_cand, st_chain, st_items);
   }
-  if (st_flags & 2) atomicAdd(&S[SS_ST_ITEMS], 1);
   if (st_flags & 4) atomicAdd(&S[SS_ST_STALLS], 1);
   if (st_flags >> 8) atomicAdd(&S[SS_ST_SKIPPED], st_flags >> 8);
 }
@@ -1125,7 +1122,7 @@ static int check_engine(const tsg_model* m, const tsg_graph* g, const tsg_od_bat
   if (g->n_roads <= 0 || g->max_degree <= 0 || !g->indptr || !g->indices || !g->cost) return TSG_E_INVALID;
   if (g->max_degree > TSG_MAX_DEGREE) return TSG_E_LIMIT;
   if (g->dist_table && !g->pair_cost) return TSG_E_INVALID;
-  if (e->slots <= 0 || e->exp_cap <= 0 || e->node_cap <= 0 || e->heap_cap <= 0) return TSG_E_INVALID;
+  if (e->slots <= 0 || e->exp_cap <= 0 || e->node_cap <= 0 || e->heap_cap <= 8 || (e->heap_cap % 8) != 0) return TSG_E_INVALID;
   if ((unsigned)e->node_cap > TSG_NODE_MASK) return TSG_E_LIMIT;
   const size_t B = (size_t)e->slots;
   if (!e->slot_state || e->slot_state_bytes < B * SS_WORDS * 4) return TSG_E_TOO_SMALL;

@@ -397,7 +397,9 @@ class AStarEngine(object):
             max_pops = int(os.environ.get('TSG_MAX_POPS', '4'))
         self.max_pops = int(max_pops)
         self.node_cap = int(min(n, 1 + self.max_step * graph.max_degree)) + 1
-        self.heap_cap = 1 + self.max_step * graph.max_degree
+        # queue entries per search: one push per successor per expansion at most, + the start node; + 1 word in front
+        # (entry i sits at word i + 1: heappop's runs are then sector-aligned), rounded to whole 64-byte sectors
+        self.heap_cap = _ceil(2 + self.max_step * graph.max_degree, 8)
         if self.node_cap >= (1 << 20):
             raise ValueError('node_cap %d exceeds 2^20-1' % self.node_cap)
         hp, nl = tables.hp, tables.n_layers
@@ -467,7 +469,7 @@ class AStarEngine(object):
         """Per-search workspaces other than state pages: queue, node records, rid table, expansion records."""
         exp_cap = max_prefix + max_step
         node_cap = min(graph.num_roads, 1 + max_step * graph.max_degree) + 1
-        heap_cap = 1 + max_step * graph.max_degree
+        heap_cap = _ceil(2 + max_step * graph.max_degree, 8)
         pps = (exp_cap + 63) // 64
         return heap_cap * 8 + graph.num_roads * 8 + node_cap * 32 + exp_cap * 16 + pps * 4 + 40 * 4 + 48 \
             + graph.max_degree * 8
@@ -600,13 +602,13 @@ class AStarEngine(object):
                     if profile_every and chunk_i % profile_every == 0:
                         # sampled chunk: drain the stream, then time every kernel of the chunk with HIP events
                         stream.synchronize()
-                        items0 = int(self.slot_state[:, 32].sum())
+                        items0 = int(self.slot_state[:, 19].sum())
                         _lib.check(L.tsg_engine_run_profiled(C.byref(m), C.byref(g), C.byref(od), C.byref(eng),
                                                              supersteps, chunk, handle, prof_ms, prof_n),
                                    'tsg_engine_run_profiled')
                         cnt = self.counters.cpu()
                         pending = []
-                        prof_items += int(self.slot_state[:, 32].sum()) - items0
+                        prof_items += int(self.slot_state[:, 19].sum()) - items0
                     else:
                         # two chunks stay in flight: the completion counter of chunk i-1 is inspected (from a pinned
                         # snapshot copied on the stream) only after chunk i has been enqueued, so the GPU never
@@ -655,11 +657,11 @@ class AStarEngine(object):
         if int(cnt[K, 6]) != 0:
             raise RuntimeError('A* engine hit a workspace cap (node/heap/exp capacity)')
         st = self.slot_state.to(torch.int64).sum(dim=0).cpu()
-        self.last_stats = {'supersteps': supersteps, 'expansions': int(cnt[K, 4]), 'model_evals': int(st[27]),
-                           'n_od': n_od, 'items': int(st[32]),
-                           'chain_sum': int(st[29]), 'cand_sum': int(st[28]), 'skipped_all_closed': int(st[31]),
+        self.last_stats = {'supersteps': supersteps, 'expansions': int(cnt[K, 4]), 'model_evals': int(st[16]),
+                           'n_od': n_od, 'items': int(st[19]),
+                           'chain_sum': int(st[18]), 'cand_sum': int(st[17]), 'skipped_all_closed': int(st[20]),
                            'prof_ms': list(prof_ms), 'prof_launches': list(prof_n), 'prof_items': prof_items,
-                           'page_waits': int(st[34]), 'restarts': int(cnt[0, 7]),
+                           'page_waits': int(st[21]), 'restarts': int(cnt[0, 7]),
                            'pool_pages': self.n_pages, 'min_free_pages': int(cnt[0, 12])}
         res = {'rid': out_rid, 'time': out_time, 'len': out_len, 'status': out_status, 'steps': out_steps}
         if poplog_cap > 0:
