@@ -84,7 +84,8 @@ typedef struct tsg_gat_desc {
   const float* bias;     /* [F] or [NH*F] (concat), may be NULL */
   const int32_t* in_ptr; /* [N+1] CSR by TARGET node, edges kept in original COO order */
   const int32_t* in_src; /* [E] source node of every incoming edge */
-  float* proj;           /* workspace [N][NH*F] */
+  float* proj;           /* workspace [N][NH*F]: the projection x . W^T, or (input-space form, below) the
+                            attention-weighted input rows [N][(NH+1)*FIN] */
   float* s_src;          /* workspace [N][NH] */
   float* s_trg;          /* workspace [N][NH] */
   float* gmax;           /* workspace [1]: global max edge score (gat.py:221) */
@@ -99,6 +100,14 @@ typedef struct tsg_gat_desc {
                             scores are computed from x (FIN multiply-adds) instead of re-reading proj */
   size_t w_att_bytes;
 } tsg_gat_desc;
+
+/* Two forms of the same layer.  With concat == 0, a learned skip projection (FIN != F), FIN <= 64, w_att given
+ * and N >= (NH+1)*FIN (so that the stacked weights fit `skip`), the layer runs in the INPUT SPACE: per head the
+ * attention-weighted sum of the FIN-wide source rows, then one product [N][(NH+1)*FIN] . [(NH+1)*FIN][F] with
+ * bias and ELU in its epilogue; the N x NH x F projection is never written.  sum_j att_j (x_j W) becomes
+ * (sum_j att_j x_j) W: equal as real numbers, rounded in another order (both forms are held to 1e-4 of the
+ * reference's output by G1/G2).  Every other case materialises the projection and adds the gathered rows in
+ * the reference's COO order. */
 
 int tsg_gat_forward(const tsg_gat_desc* d, void* stream);
 

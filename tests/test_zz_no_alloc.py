@@ -98,6 +98,13 @@ def test_static_scratch_gat_identity_skip():
     _both(torch, _lib, n=65, e=200, fin=32, nh=5, fo=32, concat=False, seed=13)     # FIN == F branch (gat.py:94-97)
 
 
+def test_static_scratch_gat_input_space_form():
+    import torch
+    from ts_trajgen_amd import _lib
+    # road-encoder shape (FIN = 30, head mean, learned skip): both entry points take the input-space form
+    _both(torch, _lib, n=900, e=2300, fin=30, nh=5, fo=128, concat=False, seed=15)
+
+
 def test_static_scratch_gat_rejects_graphs_beyond_the_array():
     import torch
     from ts_trajgen_amd import _lib

@@ -14,3 +14,9 @@ j=json.loads(l)
 print('traj/s %.0f  ms/step %.0f  supersteps %d  page_waits %d  restarts %d' % (j['value'], j['ms_per_step'], j['supersteps'], j['page_waits'], j['restarts']))
 for k,v in j['kernels'].items(): print('  %-24s %7.1f us  share %.3f  frac %.3f' % (k, v['avg_ms']*1e3, v['share'], v['frac']))
 PY
+python - <<PY
+import json
+l=[x for x in open('gpurun_out/${tag}_bench.log') if x.startswith('{')][-1]
+g=json.loads(l).get('gat_encoder')
+if g: print('  gat_encoder %.3f ms  frac %.3f' % (g['ms'], g['frac']))
+PY

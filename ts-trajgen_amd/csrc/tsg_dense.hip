@@ -40,10 +40,13 @@ __device__ __forceinline__ void mma_tile(const TileLds& t, int wave, int lane, t
 }
 
 // ------------------------------------------------------------------------------------ plain GEMM
+// 128 x 128 tile per workgroup, k in steps of 32.  The next k-step's operands are requested from global memory
+// (16-byte loads where the leading dimensions and base addresses allow: `vec` bit 0 for A, bit 1 for Bt) before
+// the matrix-core work of the current one, so that their latency runs under it.
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A, int lda,
                                                        const float* __restrict__ Bt, int ldb,
                                                        const float* __restrict__ bias, float* __restrict__ C,
-                                                       int ldc, int M, int N, int K) {
+                                                       int ldc, int M, int N, int K, int elu, int vec) {
   __shared__ TileLds t;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int row0 = blockIdx.y * BM, col0 = blockIdx.x * BN;
@@ -52,32 +55,45 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
   for (int g = 0; g < 4; ++g)
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[g][i] = 0.0f;
-  for (int k0 = 0; k0 < K; k0 += BK) {
-    // A tile: 128 rows x 32 k
+  float ra[4][4], rb[4][4];
+  const int a_r = tid >> 3, a_k = (tid & 7) * 4;   // A tile: 128 rows x 32 k, rows a_r + 32 p
+  const int b_k = tid >> 5, b_c = (tid & 31) * 4;  // B tile: 32 k x 128 cols, k rows b_k + 8 p
+  auto fetch = [&](int k0) {
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-      const int r = (tid >> 3) + 32 * p;
-      const int kc = (tid & 7) * 4;
-      const int gr = row0 + r;
+      const int gr = row0 + a_r + 32 * p, gk = k0 + a_k;
+      const float* src = A + (size_t)gr * lda + gk;
+      if ((vec & 1) && gr < M && gk + 3 < K) {
+        const float4 v = *reinterpret_cast<const float4*>(src);
+        ra[p][0] = v.x, ra[p][1] = v.y, ra[p][2] = v.z, ra[p][3] = v.w;
+      } else {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int gk = k0 + kc + i;
-        t.a[r][kc + i] = (gr < M && gk < K) ? A[(size_t)gr * lda + gk] : 0.0f;
+        for (int i = 0; i < 4; ++i) ra[p][i] = (gr < M && gk + i < K) ? src[i] : 0.0f;
       }
     }
-    // B tile: 32 k x 128 cols
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-      const int kr = (tid >> 5) + 8 * p;
-      const int cc = (tid & 31) * 4;
-      const int gk = k0 + kr;
+      const int gk = k0 + b_k + 8 * p, gc = col0 + b_c;
+      const float* src = Bt + (size_t)gk * ldb + gc;
+      if ((vec & 2) && gk < K && gc + 3 < N) {
+        const float4 v = *reinterpret_cast<const float4*>(src);
+        rb[p][0] = v.x, rb[p][1] = v.y, rb[p][2] = v.z, rb[p][3] = v.w;
+      } else {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int gc = col0 + cc + i;
-        t.b[kr][cc + i] = (gk < K && gc < N) ? Bt[(size_t)gk * ldb + gc] : 0.0f;
+        for (int i = 0; i < 4; ++i) rb[p][i] = (gk < K && gc + i < N) ? src[i] : 0.0f;
       }
+    }
+  };
+  fetch(0);
+  for (int k0 = 0; k0 < K; k0 += BK) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) t.a[a_r + 32 * p][a_k + i] = ra[p][i];
+      *reinterpret_cast<float4*>(&t.b[b_k + 8 * p][b_c]) = make_float4(rb[p][0], rb[p][1], rb[p][2], rb[p][3]);
     }
     __syncthreads();
+    if (k0 + BK < K) fetch(k0 + BK);
     mma_tile(t, wave, lane, acc);
     __syncthreads();
   }
@@ -89,20 +105,33 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int gr = row0 + wave * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
-      if (gr < M) C[(size_t)gr * ldc + gc] = acc[g][i] + bv;
+      if (gr < M) {
+        float v = acc[g][i] + bv;
+        if (elu) v = v > 0.0f ? v : expm1f(v);
+        C[(size_t)gr * ldc + gc] = v;
+      }
     }
   }
 }
 
-extern "C" int tsg_gemm_f32(const float* A, int lda, const float* Bt, int ldb, const float* bias, float* C, int ldc,
-                            int M, int N, int K, void* stream) {
+// C = act(A . Bt + bias); elu != 0 closes every element with ELU (the GAT layer's activation, gat.py:114).
+// Library-internal (tsg_gat.hip); the exported tsg_gemm_f32 is the elu == 0 case.
+int tsg_gemm_f32_act(const float* A, int lda, const float* Bt, int ldb, const float* bias, float* C, int ldc, int M,
+                     int N, int K, int elu, void* stream) {
   if (!A || !Bt || !C || M < 0 || N <= 0 || K <= 0 || lda < K || ldb < N || ldc < N) return TSG_E_INVALID;
   if (M == 0) return 0;
   dim3 grid(tsg_cdiv(N, BN), tsg_cdiv(M, BM));
   if (grid.y > 65535u) return TSG_E_LIMIT;
-  hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(256), 0, (hipStream_t)stream, A, lda, Bt, ldb, bias, C, ldc, M, N, K);
+  const int vec = ((lda % 4 == 0 && (uintptr_t)A % 16 == 0) ? 1 : 0) | ((ldb % 4 == 0 && (uintptr_t)Bt % 16 == 0) ? 2 : 0);
+  hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(256), 0, (hipStream_t)stream, A, lda, Bt, ldb, bias, C, ldc, M, N, K,
+                     elu, vec);
   TSG_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int tsg_gemm_f32(const float* A, int lda, const float* Bt, int ldb, const float* bias, float* C, int ldc,
+                            int M, int N, int K, void* stream) {
+  return tsg_gemm_f32_act(A, lda, Bt, ldb, bias, C, ldc, M, N, K, 0, stream);
 }
 
 // ------------------------------------------------------------------------------------ LSTM layer step

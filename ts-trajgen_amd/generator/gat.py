@@ -170,6 +170,16 @@ class GATLayerImp3(nn.Module):
             self._csr_key = key
         return self._csr
 
+    def _transposed_weights(self):
+        """[FIN][NH*F] copies of the two projection weights, rebuilt only when a weight has changed (in-place
+        updates bump `_version`; a re-assigned parameter has another data_ptr)."""
+        ws = (self.linear_proj.weight, self.skip_proj.weight)
+        key = tuple((w.data_ptr(), w._version, str(w.device)) for w in ws)
+        if getattr(self, '_wt_key', None) != key:
+            self._wt = tuple(w.detach().t().contiguous().float() for w in ws)
+            self._wt_key = key
+        return self._wt
+
     def _train_graph(self, edge_index, n_nodes, dev):
         key = (edge_index.data_ptr(), tuple(edge_index.shape), n_nodes, str(dev))
         if self._tg_key != key:
@@ -223,8 +233,7 @@ class GATLayerImp3(nn.Module):
         n, fin = x.shape
         nh, fo = self.num_of_heads, self.num_out_features
         in_ptr, in_src = self._graph(edge_index, n, dev)
-        w_proj_t = self.linear_proj.weight.detach().t().contiguous()
-        w_skip_t = self.skip_proj.weight.detach().t().contiguous()
+        w_proj_t, w_skip_t = self._transposed_weights()
         a_src = self.scoring_fn_source.detach().reshape(nh, fo).contiguous()
         a_trg = self.scoring_fn_target.detach().reshape(nh, fo).contiguous()
         proj = torch.empty((n, nh * fo), dtype=torch.float32, device=dev)
