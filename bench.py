@@ -305,6 +305,7 @@ def two_stage_record(net, od, device, max_step):
     from ts_trajgen_amd.generator import GeneratorV4
     from ts_trajgen_amd.search import DoubleLayerSearcher
     n_od = len(od['des'])
+    free_gb = torch.cuda.mem_get_info(torch.device(device))[0] / 1e9
     reg = synth.region_tables(net, tiles=10)
     road, cfg = build_model_cpu(net)
     road = to_device(road, cfg, device)
@@ -338,7 +339,7 @@ def two_stage_record(net, od, device, max_step):
                         'per-OD RandomState(od_id), max_step %d' % (net.num_roads, r, max_step),
             'reached_frac': reached / n_od, 'rounds': s.last_stats['rounds'],
             'road_expansions_per_od': s.last_stats['road_expansions'] / n_od,
-            'gpu_busy_frac': s.last_stats.get('gpu_busy_frac')}
+            'gpu_busy_frac': s.last_stats.get('gpu_busy_frac'), 'free_hbm_gb_at_start': free_gb}
 
 
 def main():
@@ -508,8 +509,20 @@ def main():
         if world == 1 and args.two_stage_ods > 0:
             del res
             searcher._engines.clear()         # give the page pool back before the two-stage engines are sized
-            torch.cuda.empty_cache()
-            two = two_stage_record(net2, od2, device, args.max_step)
+            import gc
+            gc.collect()                      # the engine sits in reference cycles (graph handles, closures)
+            # no empty_cache(): the two-stage engines take their workspaces out of torch's cached blocks.  Memory
+            # handed back to the driver and allocated again costs 0.3 s per 42 GB tensor on this box (4 s in all).
+            if os.environ.get('TSG_PROFILE_TWO_STAGE'):      # diagnostic: where the sub-record's time goes
+                import cProfile
+                import pstats
+                pr = cProfile.Profile()
+                pr.enable()
+                two = two_stage_record(net2, od2, device, args.max_step)
+                pr.disable()
+                pstats.Stats(pr, stream=sys.stderr).sort_stats('cumulative').print_stats(40)
+            else:
+                two = two_stage_record(net2, od2, device, args.max_step)
         recurrence = ('split-f16 x3: every fp32 operand as f16 major + f16 minor (22 significant bits), three f16 '
                       'matrix-core passes, fp32 accumulation; hidden states stored in that form, cell states fp32'
                       if args.lstm == 'split' else 'fp32 matrix cores (v_mfma_f32_32x32x2_f32)')

@@ -21,6 +21,8 @@ STATUS_UNTOUCHED, STATUS_REACHED, STATUS_FALLBACK = (_lib.STATUS_UNTOUCHED, _lib
 def _auto_slots(tables, graph, max_step, max_prefix, n_od, device, budget_frac=0.6, cap=8192):
     per = AStarEngine.bytes_per_slot(tables, graph, max_step, max_prefix)
     free, _total = torch.cuda.mem_get_info(device)
+    # what torch's caching allocator holds without using it is as available to the engine as the driver's free memory
+    free += max(0, torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device))
     fit = max(1, int(free * budget_frac) // per)
     slots = min(cap, fit, max(n_od, 1))
     if slots >= 128:
@@ -51,10 +53,19 @@ class Searcher(object):
         return self._graph
 
     def _engine(self, gen_model, slots, max_step, max_prefix, lmax, streams=1, pool_pages=None, admit_reserve=None,
-                ramp_steps=0):
+                ramp_steps=0, exact=True):
+        """The engine (device workspaces + captured graph) for a call.  exact=False (the caller left the number of
+        slots to us): an engine that is already there and at least as large in every capacity serves the call, so
+        that the rounds of a two-stage generation, whose batches shrink and whose prefixes grow, do not allocate a
+        new set of workspaces each (capacities are limits only: they never change a result)."""
         tables = gen_model.tables()
         key = (id(tables), slots, max_step, max_prefix, lmax, self.state_format, pool_pages, admit_reserve, ramp_steps)
         eng = self._engines.get(key)
+        if eng is None and not exact:
+            for k, cand in self._engines.items():
+                if (k[0] == key[0] and k[4] == lmax and k[5:] == key[5:] and cand.slots >= slots and
+                        cand.max_step >= max_step and cand.max_prefix >= max_prefix):
+                    return cand
         if eng is None:
             self._engines.clear()       # one engine's workspaces at a time
             eng = AStarEngine(tables, self.graph(), slots, max_step, max_prefix, lmax, streams,
@@ -87,7 +98,9 @@ class Searcher(object):
             prefix_ptr = prefixes[0].astype(np.int32)           # CSR form: (ptr [n+1], rid, time)
             prefix_rid = prefixes[1].astype(np.int32)
             prefix_time = prefixes[2].astype(np.int32)
-            max_prefix = (int(np.diff(prefix_ptr).max()) + 63) // 64 * 64
+            # capacity in powers of two from 64: the prefixes of a two-stage generation grow from round to round, and
+            # every new capacity is a new set of workspaces
+            max_prefix = max(64, 1 << (int(np.diff(prefix_ptr).max()) - 1).bit_length())
         else:
             lens = np.array([len(p[0]) for p in prefixes], dtype=np.int32)
             prefix_ptr = np.zeros(n_od + 1, dtype=np.int32)
@@ -98,12 +111,13 @@ class Searcher(object):
         ms = np.broadcast_to(np.asarray(max_step, dtype=np.int32), (n_od,)).copy()
         ms_cap = int(ms.max()) if n_od else 1
         tables = gen_model.tables()
-        if slots is None:
+        auto = slots is None
+        if auto:
             slots = _auto_slots(tables, self.graph(), ms_cap, max_prefix, n_od, self.device)
         if streams is None:
             streams = 1
         eng = self._engine(gen_model, int(slots), ms_cap, max_prefix, lmax, int(streams), pool_pages, admit_reserve,
-                           ramp_steps)
+                           ramp_steps, exact=not auto)
         dl = np.asarray(default_lens, dtype=np.int32)
         al = None if allow_label is None else np.broadcast_to(np.asarray(allow_label, dtype=np.int32), (n_od,))
         # a slot serves at most TSG_GEN_MAX searches per batch (rid-table generations): split huge batches
