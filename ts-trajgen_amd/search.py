@@ -109,6 +109,10 @@ class Searcher(object):
             prefix_time = np.concatenate([np.asarray(p[1], dtype=np.int32) for p in prefixes])
             max_prefix = (int(lens.max()) + 63) // 64 * 64
         ms = np.broadcast_to(np.asarray(max_step, dtype=np.int32), (n_od,)).copy()
+        # every counted step closes a road that was open (search.py:279-288, :420), so a search never takes more than
+        # num_roads steps: a larger budget cannot bind, and the capacity reserved per search follows the smaller one
+        # (a region graph of 100 nodes under max_step 5000 would otherwise reserve 80 state pages per search)
+        ms = np.minimum(ms, self.graph().num_roads + 1)
         ms_cap = int(ms.max()) if n_od else 1
         tables = gen_model.tables()
         auto = slots is None
