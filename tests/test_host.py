@@ -40,6 +40,19 @@ def test_library_exports_every_declared_symbol():
     assert lib.tsg_version() == 2
 
 
+def test_host_library_exports_every_declared_symbol():
+    """libtsg_host.so (plain C, no GPU) loads and exports what include/tsg_host.h declares."""
+    lib_path = os.path.join(ROOT, 'ts-trajgen_amd', 'csrc', 'libtsg_host.so')
+    if not os.path.exists(lib_path):
+        pytest.fail('libtsg_host.so is not built: run __graft_entry__.build()')
+    header = open(os.path.join(ROOT, 'include', 'tsg_host.h')).read()
+    declared = set(re.findall(r'^int (tsg_host_\w+)\(', header, flags=re.M))
+    assert declared == {'tsg_host_border_orders'}
+    lib = ctypes.CDLL(lib_path)
+    for name in declared:
+        assert hasattr(lib, name), name
+
+
 def test_struct_sizes_match_header(tmp_path):
     """The ctypes mirrors are as large as the C structs of include/tsg.h (compiled here with gcc)."""
     import subprocess
