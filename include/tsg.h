@@ -202,15 +202,17 @@ int tsg_gat_build_input(const float* node_features, int n_nodes, int fraw, const
  * Model tables shared by the scoring entry points (function G + function H of
  * generator/generator_v4.py:31-72, pre-factored on the host by ts-trajgen_amd/engine.py).
  * Hp = hidden size padded to a multiple of 64 (padding units have zero weights).
- * Gate columns are interleaved: col = (u/32)*128 + gate*32 + u%32, gates in torch order i,f,g,o.
+ * Gate columns of the weights (whh0_t, wl_t, bl) are interleaved: col = (u/32)*128 + gate*32 + u%32, gates in
+ * torch order i,f,g,o (one 128-column matrix-core tile holds the four gates of 32 units); the additive tables
+ * xproj / tproj keep the four gates of a unit side by side instead, col = 4*u + gate (one 16-byte read per unit).
  * ------------------------------------------------------------------------------------------ */
 typedef struct tsg_model {
   int32_t n_roads;   /* rows of out_w / pfrom / pto */
   int32_t n_time;    /* rows of tproj */
   int32_t hp;        /* padded hidden size, multiple of 64, <= 512 */
   int32_t n_layers;  /* LSTM layers, 1..TSG_MAX_LAYERS */
-  const float* xproj;                /* [n_roads+1][4Hp] road_emb . W_ih_l0[:, :Er]^T */
-  const float* tproj;                /* [n_time][4Hp]   time_emb . W_ih_l0[:, Er:]^T + b_ih_l0 + b_hh_l0 */
+  const float* xproj;                /* [n_roads+1][Hp][4] road_emb . W_ih_l0[:, :Er]^T, 16-byte aligned */
+  const float* tproj;                /* [n_time][Hp][4]   time_emb . W_ih_l0[:, Er:]^T + b_ih_l0 + b_hh_l0, 16-byte aligned */
   const float* whh0_t;               /* [Hp][4Hp]       W_hh_l0^T */
   const float* wl_t[TSG_MAX_LAYERS]; /* l>=1: [2Hp][4Hp] = [W_ih_l^T ; W_hh_l^T]; entry 0 unused */
   const float* bl[TSG_MAX_LAYERS];   /* l>=1: [4Hp] b_ih_l + b_hh_l; entry 0 unused */
@@ -327,8 +329,13 @@ typedef struct tsg_engine {
   int32_t slots;     /* B: searches in flight */
   int32_t exp_cap;   /* expanded nodes per slot  >= max prefix + max max_step */
   int32_t node_cap;  /* discovered nodes per slot (<= 2^20 - 1) */
-  int32_t heap_cap;  /* words of a slot's queue stretch: a multiple of 8, capacity heap_cap - 1 entries (entry i sits at
-                        word i + 1, which aligns the runs heappop reads to 64-byte sectors) */
+  int32_t heap_cap;  /* 8-byte words of a slot's queue stretch, a multiple of 16 (>= 32).  The queue is a blocked heap for
+                        its first twelve levels (entries 1..4095): three levels of CPython's binary heap per 64-byte
+                        block, blocks numbered like an 8-ary heap, so a sift touches one cache line per three levels;
+                        entries beyond lie behind the blocks in plain heap order.  A stretch for n entries (n = 2 +
+                        max_step * max_degree covers every search) has 4704 + (n - 4095) words for n > 4095, else
+                        8 * (blocks + 2) with blocks = (8^L - 1) / 7 + (d == 3L ? n - 8^L + 1 : 8^L), d = floor(log2 n),
+                        L = d / 3 (ts-trajgen_amd/engine.py::heap_words); the heap base must be 128-byte aligned */
   /* workspaces (caller-allocated); *_bytes are checked against the dims above */
   int32_t* slot_state;  size_t slot_state_bytes;  /* [B][40] int32 */
   uint64_t* heap;       size_t heap_bytes;        /* [B][heap_cap] {float prio; int32 node} */

@@ -152,3 +152,66 @@ def test_border_orders_equal_randomstate_choice():
             want = r.choice(pairs_a[q], len(pairs_a[q]), p=pairs_p[q], replace=False)
             got = pairs_a[q][out_idx[out_ptr[l]:out_ptr[l + 1]]]
             assert np.array_equal(want, got), (i, k)
+
+
+class _QNode(object):
+    """SearchNode's ordering (search.py:48-52): by the node's CURRENT log_prob."""
+    def __init__(self, i, lp):
+        self.i, self.lp = i, lp
+
+    def __lt__(self, other):
+        return self.lp[self.i] < other.lp[other.i]
+
+
+def _queue_script(seed, n_ops, n_nodes, grow):
+    """A random script of pushes / pops / log_prob updates with many equal priorities, and what heapq pops."""
+    import heapq
+    rng = np.random.RandomState(seed)
+    lp = np.zeros(n_nodes, dtype=np.float32)
+    objs = [_QNode(i, lp) for i in range(n_nodes)]
+    heap, lines, want = [], [], []
+    longest = 0
+    for i in range(n_nodes):
+        lp[i] = np.float32(rng.randint(0, 50)) / np.float32(8.0)
+        lines.append('U %d %r' % (i, float(lp[i])))
+    for _ in range(n_ops):
+        r = rng.rand()
+        if r < grow or not heap:
+            node = int(rng.randint(0, n_nodes))
+            prio = float(np.float32(rng.randint(0, 40)) / np.float32(4.0))       # few distinct values: ties
+            heapq.heappush(heap, (prio, objs[node]))
+            lines.append('P %r %d' % (prio, node))
+            longest = max(longest, len(heap))
+        elif r < grow + 0.05:
+            node = int(rng.randint(0, n_nodes))
+            lp[node] = np.float32(rng.randint(0, 50)) / np.float32(8.0)          # a better path found (search.py:405)
+            lines.append('U %d %r' % (node, float(lp[node])))
+        else:
+            want.append(heapq.heappop(heap)[1].i)
+            lines.append('O')
+    while heap:
+        want.append(heapq.heappop(heap)[1].i)
+        lines.append('O')
+    return '\n'.join(lines) + '\n', want, longest
+
+
+@pytest.mark.parametrize('blocked,lin_base,n_ops,grow', [
+    (4095, 8 * (585 + 2) + 8, 30000, 0.62),       # the shipped layout: the queue passes 4095 entries into the plain part
+    (63, 8 * (9 + 2) + 8, 6000, 0.55),            # two block levels only: the boundary and the plain part in every sift
+    (7, 8 * (1 + 2) + 8, 3000, 0.55),             # one block
+])
+def test_blocked_heap_equals_heapq(tmp_path, blocked, lin_base, n_ops, grow):
+    """The queue of the frontier kernel (csrc/tsg_heap.h: blocked layout, several levels per round trip) pops what
+    CPython's heapq pops, under the tuple order (priority, SearchNode) with ties broken by the CURRENT log_prob."""
+    import subprocess
+    exe = tmp_path / 'heap_harness'
+    subprocess.check_call(['g++', '-O1', '-std=c++17', '-DTSG_HEAP_BLOCKED=%d' % blocked,
+                           '-DTSG_HEAP_LIN_BASE=%d' % lin_base, '-I', os.path.join(ROOT, 'ts-trajgen_amd', 'csrc'),
+                           os.path.join(ROOT, 'tests', 'heap_harness.cpp'), '-o', str(exe)])
+    for seed in (1, 2):
+        script, want, longest = _queue_script(seed, n_ops, 512, grow)
+        assert longest > 2 * blocked                  # the queue did grow past the blocked levels
+        out = subprocess.run([str(exe), str(1 << 16), '512'], input=script, capture_output=True, text=True, check=True)
+        got = out.stdout.split('\n')
+        assert got[-2] == 'n 0'
+        assert [int(x) for x in got[:-2]] == want

@@ -146,6 +146,31 @@ enum { ND_OPEN = -1, ND_CLOSED_NOSLOT = -2 };
 // expanded-slot meta words ([B][exp_cap][4] int32)
 enum { EM_PARENT = 0, EM_RID, EM_TCODE, EM_DEPTH, EM_WORDS = 4 };
 
+// Queue stretch of a slot (tsg_engine.heap, heap_cap words of 8 bytes): a blocked heap for the first twelve levels
+// (entries 1..4095: three levels of the binary heap per 64-byte block, blocks numbered like an 8-ary heap, the
+// stretch starting one block late; heap_addr in tsg_search.hip), the entries beyond in plain heap order behind the
+// blocks.  tsg_heap_room: the number of entries a stretch of `words` words can hold (one spare block behind the
+// last one, so that a sift may read the aligned pair of blocks of an only child).
+#define TSG_HEAP_BLOCKED 4095                  /* entries in blocks: levels 0..11 */
+#define TSG_HEAP_LIN_BASE (8 * (585 + 2) + 8)  /* word of entry 4096: behind 585 blocks, the offset and the spare one */
+__host__ __device__ inline int tsg_heap_room(int words) {
+  if (words > TSG_HEAP_LIN_BASE) return TSG_HEAP_BLOCKED + (words - TSG_HEAP_LIN_BASE);
+  const long blocks = (long)words / 8 - 2;
+  long n = 0, pre = 0, p8 = 1;
+  while (p8 <= 512) {
+    if (blocks >= pre + p8) {  // every block of this block level fits: entries through three more levels
+      n = 8 * p8 - 1;
+      pre += p8;
+      p8 *= 8;
+    } else {
+      const long avail = blocks - pre;
+      if (avail > 0) n = p8 + avail - 1;
+      break;
+    }
+  }
+  return (int)n;
+}
+
 #define TSG_GEN_SHIFT 20
 #define TSG_NODE_MASK ((1u << TSG_GEN_SHIFT) - 1u)
 #define TSG_GEN_MAX 4095

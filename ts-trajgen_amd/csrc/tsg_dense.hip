@@ -255,9 +255,11 @@ __global__ __launch_bounds__(256, 2) void lstm_layer_kernel(LstmArgs a) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int r = wave * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
-      const float* xp = a.xproj + (size_t)s_rid[r] * ldw + gcol;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) acc[g][i] = xp[g * 32];
+      const float4 xv = *reinterpret_cast<const float4*>(a.xproj + (size_t)s_rid[r] * ldw + 4 * u);  // i, f, g, o of unit u
+      acc[0][i] = xv.x;
+      acc[1][i] = xv.y;
+      acc[2][i] = xv.z;
+      acc[3][i] = xv.w;
     }
   } else {
 #pragma unroll
@@ -325,8 +327,7 @@ __global__ __launch_bounds__(256, 2) void lstm_layer_kernel(LstmArgs a) {
   float4 tq[4];
   auto tload = [&](int i) {
     const int r = wave * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
-    const float* tp = a.tproj + (size_t)s_tc[r] * ldw + gcol;
-    return make_float4(tp[0], tp[32], tp[64], tp[96]);
+    return *reinterpret_cast<const float4*>(a.tproj + (size_t)s_tc[r] * ldw + 4 * u);
   };
   if (LAYER0) {
 #pragma unroll
@@ -460,9 +461,11 @@ __device__ __forceinline__ void lstm_layer_split_body(const LstmArgs& a) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int r = wave * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
-      const float* xp = a.xproj + (size_t)s_rid[r] * ldw + gcol;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) acc[g][i] = xp[g * 32] * 2048.0f;
+      const float4 xv = *reinterpret_cast<const float4*>(a.xproj + (size_t)s_rid[r] * ldw + 4 * u);  // i, f, g, o of unit u
+      acc[0][i] = xv.x * 2048.0f;
+      acc[1][i] = xv.y * 2048.0f;
+      acc[2][i] = xv.z * 2048.0f;
+      acc[3][i] = xv.w * 2048.0f;
     }
   } else {
 #pragma unroll
@@ -598,8 +601,7 @@ __device__ __forceinline__ void lstm_layer_split_body(const LstmArgs& a) {
   float4 tq[4];
   auto tload = [&](int i) {
     const int r = wave * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
-    const float* tp = a.tproj + (size_t)s_tc[r] * ldw + gcol;
-    return make_float4(tp[0], tp[32], tp[64], tp[96]);
+    return *reinterpret_cast<const float4*>(a.tproj + (size_t)s_tc[r] * ldw + 4 * u);
   };
   if (LAYER0) {
 #pragma unroll

@@ -278,141 +278,7 @@ static void launch_score_frontier(const tsg_model* m, const EngineDev& D, int su
 //     two round trips, instead of walking the parent chain one point at a time.
 // (One WAVE per search cuts the round trips further, to 10-14 per superstep, but 24 576 waves of ~1 900
 // instructions are issue-bound: 90 us per launch against this kernel's time; ablate/frontier_wave_per_search.hip.txt.)
-struct HeapEnt {
-  float prio;
-  int node;
-};
-
-__device__ __forceinline__ HeapEnt heap_ld(const uint64_t* h, int i) {
-  const uint64_t v = h[i];
-  HeapEnt e;
-  e.prio = __uint_as_float((uint32_t)v);
-  e.node = (int)(v >> 32);
-  return e;
-}
-__device__ __forceinline__ void heap_st(uint64_t* h, int i, HeapEnt e) {
-  h[i] = (uint64_t)__float_as_uint(e.prio) | ((uint64_t)(uint32_t)e.node << 32);
-}
-// (priority, SearchNode) tuple order of queue.PriorityQueue: priority, then SearchNode.__lt__ on the
-// node's CURRENT log_prob (search.py:48-52); the same node never compares less than itself.
-__device__ __forceinline__ bool ent_less(HeapEnt a, HeapEnt b, const int32_t* nodes) {
-  if (a.prio != b.prio) return a.prio < b.prio;
-  if (a.node == b.node) return false;
-  return __int_as_float(nodes[(size_t)a.node * ND_WORDS + ND_LP]) <
-         __int_as_float(nodes[(size_t)b.node * ND_WORDS + ND_LP]);
-}
-__device__ __forceinline__ HeapEnt ent_of(uint64_t v) {
-  HeapEnt e;
-  e.prio = __uint_as_float((uint32_t)v);
-  e.node = (int)(v >> 32);
-  return e;
-}
-// heapq.heappush == append + _siftdown(heap, 0, len-1).  The ancestors of the insertion point have known
-// addresses ((pos + 1) >> k) - 1, so TSG_PUSH_ANC of them are fetched per round trip instead of one.  (A push climbs
-// 0.35 levels on average; what a round trip costs grows with the number of cache lines it asks for, so fetching
-// all ancestors at once is no faster than four: ablate/chase_k.hip, DESIGN.md.)
-#ifndef TSG_PUSH_ANC
-#define TSG_PUSH_ANC 4
-#endif
-#if TSG_STAMP
-__device__ int g_cnt_dummy;
-#define HCNT(x) (x)
-#else
-#define HCNT(x)
-#endif
-__device__ __forceinline__ void heap_push(uint64_t* h, int& n, HeapEnt item, const int32_t* nodes, int* moves = nullptr) {
-  int pos = n++;
-  while (pos > 0) {
-    uint64_t av[TSG_PUSH_ANC];
-    const int base = pos + 1;
-#pragma unroll
-    for (int k = 0; k < TSG_PUSH_ANC; ++k) {
-      const int a = (base >> (k + 1)) - 1;
-      av[k] = h[a > 0 ? a : 0];
-    }
-    bool stop = false;
-#pragma unroll
-    for (int k = 0; k < TSG_PUSH_ANC; ++k) {
-      if (stop || pos == 0) continue;
-      const HeapEnt par = ent_of(av[k]);
-      if (!ent_less(item, par, nodes)) {
-        stop = true;
-      } else {
-        heap_st(h, pos, par);
-        pos = (base >> (k + 1)) - 1;
-        if (moves) ++*moves;
-      }
-    }
-    if (stop) break;
-  }
-  heap_st(h, pos, item);
-}
-// heapq.heappop == pop last, put it at the root, _siftup (bubble the smaller child up to a leaf, then
-// _siftdown).  Three levels below the current position (2 + 4 + 8 entries, contiguous per level) are
-// fetched per round trip; the decisions are the same comparisons in the same order.  _siftdown's first
-// comparison is against the entry the sift moved last, which is still in a register.
-__device__ __forceinline__ HeapEnt heap_pop(uint64_t* h, int& n, const int32_t* nodes) {
-  const HeapEnt last = heap_ld(h, n - 1);
-  --n;
-  if (n == 0) return last;
-  const HeapEnt ret = heap_ld(h, 0);
-  const int hi = n - 1;
-  int pos = 0;
-  uint64_t moved = 0;  // the entry that went from `pos` to its parent in the latest step
-  while (2 * pos + 1 < n) {
-    const int c0 = 2 * pos + 1, g0 = 4 * pos + 3, q0 = 8 * pos + 7;
-    uint64_t cv[2], gv[4], qv[8];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) cv[i] = h[c0 + i < hi ? c0 + i : hi];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) gv[i] = h[g0 + i < hi ? g0 + i : hi];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) qv[i] = h[q0 + i < hi ? q0 + i : hi];
-    // level 1
-    int s1 = 0;
-    if (c0 + 1 < n && !ent_less(ent_of(cv[0]), ent_of(cv[1]), nodes)) s1 = 1;
-    moved = cv[s1];
-    h[pos] = moved;
-    pos = c0 + s1;
-    int child = 2 * pos + 1;
-    if (child >= n) break;
-    // level 2
-    const uint64_t gl = s1 ? gv[2] : gv[0], gr = s1 ? gv[3] : gv[1];
-    int s2 = 0;
-    if (child + 1 < n && !ent_less(ent_of(gl), ent_of(gr), nodes)) s2 = 1;
-    moved = s2 ? gr : gl;
-    h[pos] = moved;
-    pos = child + s2;
-    child = 2 * pos + 1;
-    if (child >= n) break;
-    // level 3
-    const int sel = 2 * s1 + s2;
-    const uint64_t ql = sel == 0 ? qv[0] : sel == 1 ? qv[2] : sel == 2 ? qv[4] : qv[6];
-    const uint64_t qr = sel == 0 ? qv[1] : sel == 1 ? qv[3] : sel == 2 ? qv[5] : qv[7];
-    int s3 = 0;
-    if (child + 1 < n && !ent_less(ent_of(ql), ent_of(qr), nodes)) s3 = 1;
-    moved = s3 ? qr : ql;
-    h[pos] = moved;
-    pos = child + s3;
-  }
-  // _siftdown(heap, 0, pos): the parent of `pos` now holds `moved`
-  if (pos > 0) {
-    if (ent_less(last, ent_of(moved), nodes)) {
-      int pp = (pos - 1) >> 1;
-      heap_st(h, pos, ent_of(moved));
-      pos = pp;
-      while (pos > 0) {
-        pp = (pos - 1) >> 1;
-        const HeapEnt par = heap_ld(h, pp);
-        if (!ent_less(last, par, nodes)) break;
-        heap_st(h, pos, par);
-        pos = pp;
-      }
-    }
-  }
-  heap_st(h, pos, last);
-  return ret;
-}
+#include "tsg_heap.h"
 
 // A trajectory out of the expansion records of one search: (rid, tcode) is its last point (depth = its length),
 // `parent` the expanded node before it; the chain of parents fills the positions in front (search.py:291-296:
@@ -570,8 +436,8 @@ __global__ __launch_bounds__(256) void frontier_kernel(EngineDev D, int superste
   // entry i of the queue sits at word i + 1 of the slot's stretch (whose length is a multiple of 8 entries): the
   // runs heappop reads, 2 / 4 / 8 entries from 2p+1 / 4p+3 / 8p+7, are then 16- / 32- / 64-byte aligned and each
   // lies in one 64-byte sector instead of straddling two
-  uint64_t* heap = D.e.heap + (size_t)b * D.e.heap_cap + 1;
-  const int heap_room = D.e.heap_cap - 1;
+  uint64_t* heap = D.e.heap + (size_t)b * D.e.heap_cap;
+  const int heap_room = tsg_heap_room(D.e.heap_cap);
   uint64_t* table = D.e.table + (size_t)b * g.n_roads;
   int32_t* nodes = D.e.nodes + (size_t)b * D.e.node_cap * ND_WORDS;
   int32_t* em = D.e.exp_meta + (size_t)b * D.e.exp_cap * EM_WORDS;
@@ -829,7 +695,7 @@ __global__ __launch_bounds__(256) void frontier_kernel(EngineDev D, int superste
       HeapEnt he;
       he.prio = 0.0f;
       he.node = 0;
-      heap_st(heap, 0, he);
+      heap_st(heap, heap_addr(1), he);
       heap_n = 1;
       node_n = 1;
       exp_n = plen - 1;
@@ -1122,7 +988,7 @@ static int check_engine(const tsg_model* m, const tsg_graph* g, const tsg_od_bat
   if (g->n_roads <= 0 || g->max_degree <= 0 || !g->indptr || !g->indices || !g->cost) return TSG_E_INVALID;
   if (g->max_degree > TSG_MAX_DEGREE) return TSG_E_LIMIT;
   if (g->dist_table && !g->pair_cost) return TSG_E_INVALID;
-  if (e->slots <= 0 || e->exp_cap <= 0 || e->node_cap <= 0 || e->heap_cap <= 8 || (e->heap_cap % 8) != 0) return TSG_E_INVALID;
+  if (e->slots <= 0 || e->exp_cap <= 0 || e->node_cap <= 0 || e->heap_cap < 32 || (e->heap_cap % 16) != 0) return TSG_E_INVALID;
   if ((unsigned)e->node_cap > TSG_NODE_MASK) return TSG_E_LIMIT;
   const size_t B = (size_t)e->slots;
   if (!e->slot_state || e->slot_state_bytes < B * SS_WORDS * 4) return TSG_E_TOO_SMALL;

@@ -38,6 +38,30 @@ def _permute_cols(w_t, hidden, hp):
     return out
 
 
+def _unit_major_cols(w_t, hidden, hp):
+    """w_t: [K, 4*hidden] (torch gate-major columns) -> [K, 4*hp] with the four gates of a unit side by side
+    (column 4*u + gate), zero padded: the layout of tsg_model.xproj / tproj, whose rows the recurrence reads as one
+    16-byte piece per unit."""
+    out = torch.zeros((w_t.shape[0], hp, 4), dtype=torch.float32, device=w_t.device)
+    out[:, :hidden, :] = w_t.reshape(w_t.shape[0], 4, hidden).permute(0, 2, 1)
+    return out.reshape(w_t.shape[0], 4 * hp)
+
+
+def heap_words(n):
+    """8-byte words of a slot's queue stretch that holds n entries: the blocked heap of tsg_search.hip for the first
+    twelve levels (entries 1..4095: three levels of the binary heap per 64-byte block, blocks numbered like an 8-ary
+    heap, one block of offset in front and one spare block behind), the entries beyond in plain heap order behind
+    the blocks; rounded to whole 128-byte lines.  tsg_heap_room (tsg_common.h) is its inverse."""
+    n = max(int(n), 1)
+    if n > 4095:
+        return _ceil(8 * (585 + 2) + 8 + (n - 4095), 16)
+    d = n.bit_length() - 1
+    lvl = d // 3
+    p8 = 1 << (3 * lvl)
+    blocks = (p8 - 1) // 7 + ((n - p8 + 1) if d == 3 * lvl else p8)
+    return _ceil(8 * (blocks + 2), 16)
+
+
 def _pad_rows(w, rows):
     if w.shape[0] == rows:
         return w.contiguous()
@@ -99,9 +123,9 @@ class ModelTables(object):
                 raise ValueError('at most %d LSTM layers' % _lib.TSG_MAX_LAYERS)
             sd = {k: v.detach().float() for k, v in g.state_dict().items()}
             w_ih0 = sd['lstm.weight_ih_l0']                                  # (4H, Er+Et)
-            self.xproj = gemm(sd['road_emb.weight'], _permute_cols(w_ih0[:, :er].t().contiguous(), H, hp))
-            b0 = _permute_cols((sd['lstm.bias_ih_l0'] + sd['lstm.bias_hh_l0']).unsqueeze(0), H, hp).squeeze(0)
-            self.tproj = gemm(sd['time_emb.weight'], _permute_cols(w_ih0[:, er:].t().contiguous(), H, hp), b0)
+            self.xproj = gemm(sd['road_emb.weight'], _unit_major_cols(w_ih0[:, :er].t().contiguous(), H, hp))
+            b0 = _unit_major_cols((sd['lstm.bias_ih_l0'] + sd['lstm.bias_hh_l0']).unsqueeze(0), H, hp).squeeze(0)
+            self.tproj = gemm(sd['time_emb.weight'], _unit_major_cols(w_ih0[:, er:].t().contiguous(), H, hp), b0)
             self.whh0_t = _pad_rows(_permute_cols(sd['lstm.weight_hh_l0'].t().contiguous(), H, hp), hp)
             self.wl_t = [None] * _lib.TSG_MAX_LAYERS
             self.bl = [None] * _lib.TSG_MAX_LAYERS
@@ -397,9 +421,9 @@ class AStarEngine(object):
             max_pops = int(os.environ.get('TSG_MAX_POPS', '4'))
         self.max_pops = int(max_pops)
         self.node_cap = int(min(n, 1 + self.max_step * graph.max_degree)) + 1
-        # queue entries per search: one push per successor per expansion at most, + the start node; + 1 word in front
-        # (entry i sits at word i + 1: heappop's runs are then sector-aligned), rounded to whole 64-byte sectors
-        self.heap_cap = _ceil(2 + self.max_step * graph.max_degree, 8)
+        # queue entries per search: one push per successor per expansion at most, + the start node
+        self.heap_entries = 2 + self.max_step * graph.max_degree
+        self.heap_cap = heap_words(self.heap_entries)       # words of the slot's stretch (blocked heap)
         if self.node_cap >= (1 << 20):
             raise ValueError('node_cap %d exceeds 2^20-1' % self.node_cap)
         hp, nl = tables.hp, tables.n_layers
@@ -469,7 +493,7 @@ class AStarEngine(object):
         """Per-search workspaces other than state pages: queue, node records, rid table, expansion records."""
         exp_cap = max_prefix + max_step
         node_cap = min(graph.num_roads, 1 + max_step * graph.max_degree) + 1
-        heap_cap = _ceil(2 + max_step * graph.max_degree, 8)
+        heap_cap = heap_words(2 + max_step * graph.max_degree)
         pps = (exp_cap + 63) // 64
         return heap_cap * 8 + graph.num_roads * 8 + node_cap * 32 + exp_cap * 16 + pps * 4 + 40 * 4 + 48 \
             + graph.max_degree * 8
@@ -593,7 +617,7 @@ class AStarEngine(object):
             # every superstep each unfinished slot advances by >= 1 expansion / prefix element / finished OD
             per_search = self.max_step + self.max_prefix + 4    # + the write-out superstep and the idle one behind it
             if self.max_pops > 0:       # yields: at most heap_cap pops per search, max_pops of them per superstep
-                per_search += self.heap_cap // self.max_pops + 1
+                per_search += self.heap_entries // self.max_pops + 1
             bound = (math.ceil(n_od / self.slots) + 1) * per_search + 8 + self.ramp_steps
             if self.n_pages < self.slots * self.pages_per_slot:     # searches may wait for pages or restart
                 bound = 4 * bound + 8 * math.ceil(n_od * self.pages_per_slot / self.n_pages) * per_search
