@@ -59,6 +59,36 @@ def test_g1_gat_layer(case):
     np.testing.assert_allclose(out.cpu().numpy(), z['%s_out' % case], rtol=RTOL, atol=1e-5)
 
 
+@pytest.mark.parametrize('fin,nh,fo', [(30, 5, 256), (48, 3, 64), (64, 2, 128)])
+def test_gat_layer_input_space_form_against_oracle(fin, nh, fo):
+    """The road encoder's form of the layer (heads averaged, FIN <= 64, N >= (NH+1) FIN: attention-weighted sums of the
+    input rows, then one product; tsg_gat.hip) against the oracle's restatement of gat.py:138-200 on a graph with
+    what the goldens' graph has (duplicate edges, self loops, nodes without incoming edges) plus hubs whose
+    in-degree exceeds one pass of the kernel's lane group (32 or 64 edges)."""
+    from oracle.model import gat_forward
+    from ts_trajgen_amd.generator import GATLayerImp3
+    g = torch.Generator().manual_seed(fin * 100 + nh)
+    n = 700
+    src = torch.randint(0, n, (2400,), generator=g)
+    trg = torch.randint(40, n, (2400,), generator=g)              # nodes 0..39: no incoming edge
+    hub_src = torch.randint(0, n, (230,), generator=g)
+    hub_trg = torch.cat([torch.full((150,), 50), torch.full((80,), 51)]).long()      # in-degree 150+ and 80+
+    loops = torch.arange(60, 90)
+    ei = torch.stack([torch.cat([src, hub_src, loops, src[:50]]), torch.cat([trg, hub_trg, loops, trg[:50]])])
+    ei = ei[:, torch.randperm(ei.shape[1], generator=g)].contiguous()
+    x = torch.randn((n, fin), generator=g)
+    layer = GATLayerImp3(fin, fo, nh, DEV, concat=False)
+    with torch.no_grad():
+        layer.bias.copy_(torch.randn(layer.bias.shape, generator=g) * 0.1)
+    want = gat_forward(x, ei, layer.linear_proj.weight.detach(), layer.skip_proj.weight.detach(),
+                       layer.scoring_fn_source.detach(), layer.scoring_fn_target.detach(), layer.bias.detach(),
+                       nh, fo, concat=False)
+    layer = layer.to(DEV).train(False)
+    out, _ = layer((x.to(DEV), ei.to(DEV)))
+    want = want.detach().numpy()
+    np.testing.assert_allclose(out.cpu().numpy(), want, rtol=RTOL, atol=1e-5 * max(1.0, float(np.abs(want).max())))
+
+
 GAT_PARAMS = ('linear_proj.weight', 'skip_proj.weight', 'scoring_fn_source', 'scoring_fn_target', 'bias')
 
 
