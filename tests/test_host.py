@@ -37,7 +37,16 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), name
     from ts_trajgen_amd import _lib
     assert set(_lib.EXPORTS) == declared
-    assert lib.tsg_version() == 2
+    assert lib.tsg_version() == _lib.ABI_VERSION == 2
+    header_version = int(re.search(r'#define TSG_ABI_VERSION (\d+)', header).group(1))
+    assert header_version == _lib.ABI_VERSION
+
+
+def test_build_entry_point_runs():
+    """__graft_entry__.build() is what the driver calls on the CPU every round: make is a no-op on a built tree, the
+    package imports and both libraries load."""
+    import __graft_entry__ as g
+    g.build()
 
 
 def test_host_library_exports_every_declared_symbol():

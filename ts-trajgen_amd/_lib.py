@@ -15,6 +15,7 @@ TSG_H_HIDDEN = 10
 STATUS_UNTOUCHED, STATUS_REACHED, STATUS_FALLBACK, STATUS_OVERFLOW = 0, 1, 2, 0x100
 GAT_STATIC_SCRATCH_BYTES = 8 << 20     # TSG_GAT_STATIC_SCRATCH_BYTES
 
+ABI_VERSION = 2         # TSG_ABI_VERSION of include/tsg.h
 EXPORTS = ('tsg_version', 'tsg_gemm_f32', 'tsg_gat_forward', 'tsg_gat_forward_static', 'tsg_gat_train_forward', 'tsg_gat_train_backward', 'tsg_gat_build_input', 'tsg_lstm_step_batched',
            'tsg_score_candidates', 'tsg_engine_reset', 'tsg_engine_run', 'tsg_engine_run_profiled', 'tsg_engine_graph_create', 'tsg_engine_graph_launch',
            'tsg_engine_graph_destroy', 'tsg_frontier_expand_select',
@@ -122,6 +123,9 @@ def lib():
         if not hasattr(L, name):
             raise RuntimeError('libtsg.so lacks symbol %s (stale build?)' % name)
     L.tsg_version.restype = C.c_int
+    if L.tsg_version() != ABI_VERSION:      # struct layouts of this file are those of include/tsg.h at that version
+        raise RuntimeError('libtsg.so has ABI version %d, this binding expects %d (stale build?)'
+                           % (L.tsg_version(), ABI_VERSION))
     L.tsg_gemm_f32.argtypes = [_p, C.c_int, _p, C.c_int, _p, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p]
     L.tsg_gat_forward.argtypes = [C.POINTER(GatDesc), _p]
     L.tsg_gat_forward_static.argtypes = [C.POINTER(GatDesc), _p]
