@@ -244,6 +244,37 @@ def test_config1_work_list_over_several_regions(porto):
     assert torch.equal(got['rid'][:half], got['rid'][half:])       # the same OD pair twice: the same trajectory
 
 
+def test_config1_engines_on_two_and_three_streams(porto):
+    """`streams` = E: the OD pairs dealt over E engines that run side by side from E host threads (Searcher.generate)
+    give the trajectories of one engine, bit for bit, in the caller's order, also with prefixes of several
+    elements, a page pool under pressure and an odd number of OD pairs."""
+    from ts_trajgen_amd.search import Searcher
+    net, model, cfg, od = porto
+    s = Searcher(DEV, net.adjacent_list, net.rid_gps, net.road_length, net.road_time_distribution)
+    sub = slice(0, 1001)
+    args = (model, od['start'][sub], od['start_time'][sub], od['des'][sub], od['default_len'][sub])
+    ref = s.generate(*args, max_step=1500, slots=256, lmax=256)
+    one = dict(s.last_stats)
+    pps = (1 + 1500 + 63) // 64
+    for n_eng, kw in ((2, {}), (3, {}), (2, {'pool_pages': 96 * pps, 'ramp_steps': 300})):
+        got = s.generate(*args, max_step=1500, slots=768, lmax=256, streams=n_eng, **kw)
+        st = dict(s.last_stats)
+        assert st['engines'] == n_eng and st['expansions'] == one['expansions'] and st['n_od'] == 1001
+        for k in ('rid', 'time', 'len', 'status', 'steps'):
+            assert torch.equal(ref[k], got[k]), (n_eng, k)
+    # multi-element prefixes (the legs of the two-stage search): continue every trajectory from its first 3 points
+    ln = ref['len'].numpy()
+    keep = np.flatnonzero(ln >= 5)[:300]
+    ptr = np.arange(len(keep) + 1, dtype=np.int32) * 3
+    p_rid = ref['rid'].numpy()[keep, :3].reshape(-1)
+    p_tim = ref['time'].numpy()[keep, :3].reshape(-1)
+    a2 = (model, None, None, od['des'][sub][keep], od['default_len'][sub][keep])
+    r1 = s.generate(*a2, max_step=800, prefixes=(ptr, p_rid, p_tim), slots=128, lmax=256)
+    r2 = s.generate(*a2, max_step=800, prefixes=(ptr, p_rid, p_tim), slots=256, lmax=256, streams=2)
+    for k in ('rid', 'time', 'len', 'status', 'steps'):
+        assert torch.equal(r1[k], r2[k]), k
+
+
 # ---- BASELINE.json configs[2]: the BJ-scale graph (N = 40 306, E = 100 000), the config the target is quoted on
 @pytest.fixture(scope='module')
 def bj():

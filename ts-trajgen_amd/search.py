@@ -86,7 +86,9 @@ class Searcher(object):
         max_step: int or per-OD array.  Returns dict with padded `rid`/`time` [n, lmax], `len`, `status`,
         `steps` (torch tensors).
         pool_pages / admit_reserve / ramp_steps: state-page pool of the engine (AStarEngine.__init__); the default
-        reserves the worst case for every search in flight."""
+        reserves the worst case for every search in flight.
+        streams: E > 1 deals the OD pairs over E engines that run side by side (`slots` and `pool_pages` are the
+        totals over all of them; _generate_engines); the results do not depend on it."""
         des = np.asarray(des_rids, dtype=np.int32)
         n_od = len(des)
         if prefixes is None:
@@ -118,12 +120,30 @@ class Searcher(object):
         auto = slots is None
         if auto:
             slots = _auto_slots(tables, self.graph(), ms_cap, max_prefix, n_od, self.device)
-        if streams is None:
-            streams = 1
-        eng = self._engine(gen_model, int(slots), ms_cap, max_prefix, lmax, int(streams), pool_pages, admit_reserve,
-                           ramp_steps, exact=not auto)
+        n_eng = max(1, int(streams or 1))
         dl = np.asarray(default_lens, dtype=np.int32)
         al = None if allow_label is None else np.broadcast_to(np.asarray(allow_label, dtype=np.int32), (n_od,))
+        run_kw = dict(poplog_cap=poplog_cap, return_device=return_device, profile_every=profile_every)
+        if n_eng > 1 and n_od >= 4 * n_eng and int(slots) >= 2 * n_eng:
+            return self._generate_engines(gen_model, n_eng, int(slots), ms_cap, max_prefix, lmax, pool_pages,
+                                          admit_reserve, ramp_steps, prefix_ptr, prefix_rid, prefix_time, des, dl, ms, al,
+                                          run_kw)
+        eng = self._engine(gen_model, int(slots), ms_cap, max_prefix, lmax, 1, pool_pages, admit_reserve,
+                           ramp_steps, exact=not auto)
+        res, self.last_stats = self._run_engine(eng, prefix_ptr, prefix_rid, prefix_time, des, dl, ms, al, run_kw)
+        return res
+
+    @staticmethod
+    def _merge_stats(stats):
+        if len(stats) == 1:
+            return stats[0]
+        lows = ('min_free_pages',)
+        return {k: ([sum(x) for x in zip(*[s[k] for s in stats])] if isinstance(stats[0][k], list)
+                    else min(s[k] for s in stats) if k in lows else sum(s[k] for s in stats)) for k in stats[0]}
+
+    def _run_engine(self, eng, prefix_ptr, prefix_rid, prefix_time, des, dl, ms, al, run_kw):
+        """All OD pairs of the arrays through one engine; returns (result dict, statistics)."""
+        n_od = len(des)
         # a slot serves at most TSG_GEN_MAX searches per batch (rid-table generations): split huge batches
         per_run = max(1, eng.slots) * 3000
         parts, stats = [], []
@@ -132,16 +152,74 @@ class Searcher(object):
             sub_ptr = prefix_ptr[lo:hi + 1] - prefix_ptr[lo]
             p0, p1 = int(prefix_ptr[lo]), int(prefix_ptr[hi])
             parts.append(eng.run(sub_ptr, prefix_rid[p0:p1], prefix_time[p0:p1], des[lo:hi], dl[lo:hi], ms[lo:hi],
-                                 allow_label=None if al is None else al[lo:hi], poplog_cap=poplog_cap,
-                                 return_device=return_device, profile_every=profile_every))
+                                 allow_label=None if al is None else al[lo:hi], **run_kw))
             stats.append(eng.last_stats)
         if len(parts) == 1:
-            res = parts[0]
-            self.last_stats = stats[0]
-        else:
-            res = {k: torch.cat([p[k] for p in parts], dim=0) for k in parts[0]}
-            self.last_stats = {k: (sum(s[k] for s in stats) if not isinstance(stats[0][k], list)
-                                   else [sum(x) for x in zip(*[s[k] for s in stats])]) for k in stats[0]}
+            return parts[0], stats[0]
+        return {k: torch.cat([p[k] for p in parts], dim=0) for k in parts[0]}, self._merge_stats(stats)
+
+    def _generate_engines(self, gen_model, n_eng, slots, ms_cap, max_prefix, lmax, pool_pages, admit_reserve, ramp_steps,
+                          prefix_ptr, prefix_rid, prefix_time, des, dl, ms, al, run_kw):
+        """`streams` = E > 1: the OD pairs are dealt round-robin over E independent engines (slots / E searches in
+        flight and pool_pages / E state pages each), every engine driven by a host thread of its own on a stream of
+        its own.  The GPU then has the launches of E supersteps to choose from: the latency-bound ones of one engine
+        (frontier, layer 0 of the recurrence) run under the matrix-core- and bandwidth-bound ones of another.  OD
+        pairs are independent, so the results are those of one engine (tests/test_gpu_fullsize.py), returned in
+        the caller's order.  Measured at BJ scale, 24 576 searches in flight: 19.2k -> 21.2k trajectories/s with two
+        engines; three or more lose to the smaller launches."""
+        import threading
+        tables = gen_model.tables()
+        n_od = len(des)
+        slots_each = max(1, slots // n_eng)
+        if slots_each >= 128:
+            slots_each = slots_each // 128 * 128
+        pool_each = None if pool_pages is None else max(1, int(pool_pages) // n_eng)
+        reserve_each = None if admit_reserve is None else max(0, int(admit_reserve) // n_eng)
+        key = ('set', id(tables), n_eng, slots_each, ms_cap, max_prefix, lmax, self.state_format, pool_each,
+               reserve_each, ramp_steps)
+        engines = self._engines.get(key)
+        if engines is None:
+            self._engines.clear()
+            engines = [AStarEngine(tables, self.graph(), slots_each, ms_cap, max_prefix, lmax, 1,
+                                   state_format=self.state_format, pool_pages=pool_each, admit_reserve=reserve_each,
+                                   ramp_steps=ramp_steps) for _ in range(n_eng)]
+            self._engines[key] = engines
+        plen = np.diff(prefix_ptr).astype(np.int64)
+        out, err = [None] * n_eng, [None] * n_eng
+        idx = [np.arange(e, n_od, n_eng) for e in range(n_eng)]
+
+        def work(e):
+            try:
+                with torch.cuda.device(self.device):
+                    ii = idx[e]
+                    ln = plen[ii]
+                    ptr = np.zeros(len(ii) + 1, dtype=np.int32)
+                    np.cumsum(ln, out=ptr[1:])
+                    # positions of the chosen prefixes' elements in the flat arrays
+                    pos = np.repeat(prefix_ptr[:-1][ii].astype(np.int64) - ptr[:-1], ln) + np.arange(int(ptr[-1]))
+                    out[e] = self._run_engine(engines[e], ptr, prefix_rid[pos], prefix_time[pos], des[ii], dl[ii], ms[ii],
+                                              None if al is None else al[ii], run_kw)
+            except BaseException as ex:      # re-raised in the calling thread
+                err[e] = ex
+
+        threads = [threading.Thread(target=work, args=(e,)) for e in range(n_eng)]
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join()
+        for ex in err:
+            if ex is not None:
+                raise ex
+        res = {}
+        for k in out[0][0]:
+            first = out[0][0][k]
+            full = torch.zeros((n_od,) + tuple(first.shape[1:]), dtype=first.dtype, device=first.device)
+            for e in range(n_eng):
+                full[torch.from_numpy(idx[e]).to(first.device)] = out[e][0][k]
+            res[k] = full
+        self.last_stats = self._merge_stats([o[1] for o in out])
+        self.last_stats['supersteps'] = max(o[1]['supersteps'] for o in out)
+        self.last_stats['engines'] = n_eng
         return res
 
     # -- reference API (one OD per call) ---------------------------------------------------------
