@@ -64,6 +64,11 @@ def parse():
     ap.add_argument('--cpu-seconds', type=float, default=25.0,
                     help='CPU baseline: no new OD pair is started after this many seconds (0 = skip)')
     ap.add_argument('--cpu-ods', type=int, default=64, help='CPU baseline: the fixed sample = first k OD pairs')
+    ap.add_argument('--engines', type=int, default=1,
+                    help='independent engines side by side in the timed step (Searcher.generate streams=E); the '
+                         'default line keeps one, so that its per-kernel times are those of undisturbed launches')
+    ap.add_argument('--two-engines', type=int, default=1,
+                    help='N = 1: also time one step of the same workload on two engines (sub-record; 0 = skip)')
     ap.add_argument('--two-stage-ods', type=int, default=16384,
                     help='OD pairs of the two-stage sub-record (configs[3], N = 1 only; 0 = skip)')
     return ap.parse_args()
@@ -403,7 +408,8 @@ def main():
     def one_step(o, profile_every=0):
         res = searcher.generate(model, o['start'], o['start_time'], o['des'], o['default_len'],
                                 max_step=args.max_step, slots=slots, lmax=args.lmax, return_device=True,
-                                profile_every=profile_every, pool_pages=pool_pages, ramp_steps=ramp)
+                                profile_every=profile_every, pool_pages=pool_pages, ramp_steps=ramp,
+                                streams=args.engines)
         if world > 1:   # the single exchange step of the path: collect the padded trajectories (RCCL over xGMI)
             from ts_trajgen_amd.distributed import gather_results, pack_rows
             n_call = n_total if o is od else len(o['des']) * world
@@ -505,6 +511,34 @@ def main():
                 peaks['f16_gemm_TFLOPs'] / 3.0 if args.lstm == 'split' and 'f16_gemm_TFLOPs' in peaks else None)
             k['measured_peak'] = ref      # this box: device-to-device copy / a third of an 8192^3 f16 matmul
             k['frac_of_measured'] = k['achieved'] / ref if ref else None
+        dual = None
+        if world == 1 and args.two_engines and args.engines == 1 and n_local >= 8:
+            # the same step on two engines side by side (Searcher.generate streams=2: half the searches in flight and
+            # half the page pool each, two host threads, two streams): whole-job throughput of that configuration,
+            # and its results against the single-engine step's
+            import gc
+            searcher._engines.clear()
+            gc.collect()
+            searcher.generate(model, od_warm['start'], od_warm['start_time'], od_warm['des'], od_warm['default_len'],
+                              max_step=args.max_step, slots=slots, lmax=args.lmax, return_device=True,
+                              pool_pages=pool_pages, ramp_steps=ramp, streams=2)
+            torch.cuda.synchronize()
+            t1 = time.time()
+            res2 = searcher.generate(model, od['start'], od['start_time'], od['des'], od['default_len'],
+                                     max_step=args.max_step, slots=slots, lmax=args.lmax, return_device=True,
+                                     pool_pages=pool_pages, ramp_steps=ramp, streams=2)
+            torch.cuda.synchronize()
+            dt2 = time.time() - t1
+            st2 = searcher.last_stats
+            dual = {'value': n_local / dt2, 'unit': 'trajectories/s', 'engines': 2, 'seconds': dt2,
+                    'searches_in_flight_per_engine': slots // 2 // 128 * 128, 'supersteps': st2['supersteps'],
+                    'page_waits': st2['page_waits'], 'restarts': st2['restarts'],
+                    'identical_to_single_engine': bool(all(torch.equal(res[k], res2[k])
+                                                           for k in ('rid', 'time', 'len', 'status', 'steps'))),
+                    'note': 'same workload and sizes as the timed step; latency-bound launches of one engine run '
+                            'under the matrix-core / bandwidth-bound launches of the other (bench.py --engines 2 makes '
+                            'it the timed step)'}
+            del res2
         two = None
         if world == 1 and args.two_stage_ods > 0:
             del res
@@ -538,6 +572,7 @@ def main():
                        'baseline_config': {'bj': 'configs[2]', 'porto': 'configs[1]', 'grid': 'configs[0]',
                                            'stress': 'configs[4]'}[args.config],
                        'od_pairs_per_step': n_total, 'od_pairs_per_gpu': n_local, 'slots_in_flight': slots,
+                       'engines': args.engines,
                        'state_pool_pages': pool_pages, 'state_pool_gb': pool_pages * page / 1e9, 'lstm': args.lstm,
                        'recurrence': recurrence, 'parallelism': 'od-shard x%d' % world},
             'expansions_per_s': exp_all / dt, 'expansions_per_od': exp_all / n_done,
@@ -550,7 +585,7 @@ def main():
             'supersteps': int(sum(s['supersteps'] for s in stats)), 'work_items': int(items),
             'page_waits': int(sum(s['page_waits'] for s in stats)), 'restarts': int(sum(s['restarts'] for s in stats)),
             'min_free_pages': int(min(s['min_free_pages'] for s in stats)),
-            'roofline': roofline, 'kernels': kern, 'measured_peaks': peaks, 'gat_encoder': gat, 'cpu_baseline': cpu,
+            'roofline': roofline, 'kernels': kern, 'measured_peaks': peaks, 'gat_encoder': gat, 'cpu_baseline': cpu, 'two_engines': dual,
             'two_stage': two,
         }
         print(json.dumps(out))
