@@ -373,6 +373,9 @@ def test_g7_double_layer(road, road_model, region):
     assert max(len(x) for x in loc) > 4
     assert loc2 == loc and tim2 == tim and fl2 == fl
     assert s2.generate(region_model, road_model, [], [], [], []) == ([], [], [])       # an empty shard
+    for n_eng in (1, 2):                                                               # the road-level entry, empty too
+        e0 = s2.road_search.generate(road_model, [], [], [], [], max_step=10, slots=8, streams=n_eng)
+        assert tuple(e0['rid'].shape) == (0, 256) and e0['len'].numel() == 0 and e0['status'].numel() == 0
     # reference one-OD signature with the global numpy RNG (search.py:859)
     c = cases[3]
     np.random.seed(c['seed'])
