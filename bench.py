@@ -377,10 +377,17 @@ def main():
 
     import torch
     import torch.distributed as dist
-    device = 'cuda:%d' % local_rank
-    torch.cuda.set_device(local_rank)
+    # rehearsal hooks (a one-GPU box): TSG_BENCH_DEVICE puts every rank on that device, TSG_BENCH_BACKEND=gloo
+    # replaces RCCL, which refuses two ranks on one GPU; the driver's multi-GPU runs set neither
+    dev_index = int(os.environ.get('TSG_BENCH_DEVICE', local_rank))
+    backend = os.environ.get('TSG_BENCH_BACKEND', 'nccl')
+    device = 'cuda:%d' % dev_index
+    torch.cuda.set_device(dev_index)
     if world > 1:
-        dist.init_process_group('nccl', device_id=torch.device(device))
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device(device))
+        else:
+            dist.init_process_group(backend)
     from ts_trajgen_amd.search import Searcher
     model = to_device(model, cfg, device)
     searcher = Searcher(device, net.adjacent_list, net.rid_gps, net.road_length, net.road_time_distribution)
