@@ -433,9 +433,7 @@ __global__ __launch_bounds__(256) void frontier_kernel(EngineDev D, int superste
   CKPT(0);  // first round trip
   int32_t itw[IT_WORDS] = {0};  // the work item of this superstep, if one is emitted: written to the work list at the end
   int32_t* shared = D.e.shared_counters;  // OD queue + completion, common to all sub-engines of a batch
-  // entry i of the queue sits at word i + 1 of the slot's stretch (whose length is a multiple of 8 entries): the
-  // runs heappop reads, 2 / 4 / 8 entries from 2p+1 / 4p+3 / 8p+7, are then 16- / 32- / 64-byte aligned and each
-  // lies in one 64-byte sector instead of straddling two
+  // the slot's queue stretch: a blocked heap (tsg_heap.h), heap_cap words
   uint64_t* heap = D.e.heap + (size_t)b * D.e.heap_cap;
   const int heap_room = tsg_heap_room(D.e.heap_cap);
   uint64_t* table = D.e.table + (size_t)b * g.n_roads;
