@@ -523,9 +523,7 @@ def main():
             # the same step on two engines side by side (Searcher.generate streams=2: half the searches in flight and
             # half the page pool each, two host threads, two streams): whole-job throughput of that configuration,
             # and its results against the single-engine step's
-            import gc
-            searcher._engines.clear()
-            gc.collect()
+            searcher._drop_engines()
             searcher.generate(model, od_warm['start'], od_warm['start_time'], od_warm['des'], od_warm['default_len'],
                               max_step=args.max_step, slots=slots, lmax=args.lmax, return_device=True,
                               pool_pages=pool_pages, ramp_steps=ramp, streams=2)
@@ -549,9 +547,7 @@ def main():
         two = None
         if world == 1 and args.two_stage_ods > 0:
             del res
-            searcher._engines.clear()         # give the page pool back before the two-stage engines are sized
-            import gc
-            gc.collect()                      # the engine sits in reference cycles (graph handles, closures)
+            searcher._drop_engines()          # give the page pool back before the two-stage engines are sized
             # no empty_cache(): the two-stage engines take their workspaces out of torch's cached blocks.  Memory
             # handed back to the driver and allocated again costs 0.3 s per 42 GB tensor on this box (4 s in all).
             if os.environ.get('TSG_PROFILE_TWO_STAGE'):      # diagnostic: where the sub-record's time goes

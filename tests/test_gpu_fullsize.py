@@ -275,6 +275,21 @@ def test_config1_engines_on_two_and_three_streams(porto):
         assert torch.equal(r1[k], r2[k]), k
 
 
+def test_config1_sizes_left_to_the_searcher(porto, monkeypatch):
+    """A large plain batch with no sizes given: Searcher.generate takes plan_engine's sizes and two engines; same
+    trajectories as with explicit sizes."""
+    from ts_trajgen_amd import search as tsg_search
+    net, model, cfg, od = porto
+    s = tsg_search.Searcher(DEV, net.adjacent_list, net.rid_gps, net.road_length, net.road_time_distribution)
+    args = (model, od['start'], od['start_time'], od['des'], od['default_len'])
+    ref = s.generate(*args, max_step=800, slots=512, lmax=256)
+    monkeypatch.setattr(tsg_search, 'AUTO_PLAN_MIN_OD', 1000)
+    got = s.generate(*args, max_step=800, lmax=256)
+    assert s.last_stats['engines'] == 2 and s.last_stats['n_od'] == len(od['des'])
+    for k in ('rid', 'time', 'len', 'status', 'steps'):
+        assert torch.equal(ref[k], got[k]), k
+
+
 # ---- BASELINE.json configs[2]: the BJ-scale graph (N = 40 306, E = 100 000), the config the target is quoted on
 @pytest.fixture(scope='module')
 def bj():

@@ -224,3 +224,19 @@ def test_blocked_heap_equals_heapq(tmp_path, blocked, lin_base, n_ops, grow):
         got = out.stdout.split('\n')
         assert got[-2] == 'n 0'
         assert [int(x) for x in got[:-2]] == want
+
+
+def test_plan_engine_sizes():
+    """Sizes Searcher.generate picks for a large batch (search.plan_engine): the bench's arithmetic."""
+    from ts_trajgen_amd.search import plan_engine
+    page, pps, fixed = 279040, 80, 1003140
+    slots, pool, ramp = plan_engine(306e9, fixed, page, pps, 131072, 2080)
+    assert slots == 24576 and ramp == 1500                      # the cap binds, the pool is below the worst case
+    assert slots * fixed + pool * page + 131072 * 2080 <= 0.93 * 306e9 < slots * fixed + (pool + 1) * page + 131072 * 2080
+    s2, p2, r2 = plan_engine(306e9, fixed, page, pps, 3000, 2080)
+    assert s2 == 2048 and p2 == s2 * pps and r2 == 0            # fewer OD pairs than places: worst case reserved
+    s3, p3, r3 = plan_engine(40e9, fixed, page, pps, 10 ** 6, 2080)
+    assert 1024 <= s3 < 24576 and s3 % 1024 == 0 and p3 < s3 * pps and r3 == 1500
+    assert s3 * fixed + p3 * page <= 0.93 * 40e9 - 10 ** 6 * 2080
+    s4, p4, r4 = plan_engine(1e9, fixed, page, pps, 10 ** 6, 2080)   # next to nothing free: one whole search at least
+    assert s4 >= 1 and p4 >= pps

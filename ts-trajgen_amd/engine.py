@@ -407,7 +407,7 @@ class AStarEngine(object):
     PAGE_ROWS = 64      # TSG_PAGE_ROWS
 
     def __init__(self, tables, graph, slots, max_step, max_prefix=1, lmax=256, streams=1, prune=True, use_graph=True,
-                 state_format=1, max_pops=None, pool_pages=None, admit_reserve=None, ramp_steps=0):
+                 state_format=1, max_pops=None, pool_pages=None, admit_reserve=None, ramp_steps=0, stream=None):
         """pool_pages: state pages (64 rows each) shared by all searches; None reserves the worst case
         (slots * ceil(exp_cap / 64): no search ever waits).  A smaller pool lets more searches fit in HBM (a
         search holds only the pages it has filled); see include/tsg.h, tsg_engine."""
@@ -481,12 +481,23 @@ class AStarEngine(object):
         e.counters_bytes = 64
         e.shared_counters = self.counters[1].data_ptr()
         self.c_engines = [e]
-        self.side_streams = [torch.cuda.Stream(device=dev)]
+        # `stream`: the stream this engine launches on (a Searcher that runs several engines side by side keeps one
+        # stream per engine for its whole life: which hardware queue a new stream lands on is the runtime's choice,
+        # and two engines whose streams share a queue do not overlap)
+        self.side_streams = [stream if stream is not None else torch.cuda.Stream(device=dev)]
         self.use_graph = bool(use_graph) and os.environ.get('TSG_NO_GRAPH', '') != '1'   # env: diagnostics only
         self.state_format = int(state_format)
         self.split_calls = False        # tests: drive the supersteps through tsg_frontier_expand_select + tsg_score_frontier
         self._pinned = [torch.zeros((2, 16), dtype=i32).pin_memory() for _ in range(2)]
         self.last_stats = {}
+
+    def close(self):
+        """Give the workspaces back now (the object may sit in reference cycles, and a Searcher that replaces its
+        engine needs the memory before the garbage collector would get to it)."""
+        for name, val in list(self.__dict__.items()):
+            if torch.is_tensor(val) or (isinstance(val, list) and val and all(torch.is_tensor(v) for v in val)):
+                setattr(self, name, None)
+        self.c_engines = []
 
     @staticmethod
     def fixed_bytes_per_slot(graph, max_step, max_prefix=1):

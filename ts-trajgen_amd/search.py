@@ -30,6 +30,30 @@ def _auto_slots(tables, graph, max_step, max_prefix, n_od, device, budget_frac=0
     return int(slots)
 
 
+def plan_engine(free_bytes, fixed_per_slot, page_bytes, pages_per_search, n_od, out_bytes_per_od, oversub=2.2,
+                cap=24576, budget_frac=0.93):
+    """Sizes for a large batch of road-level searches when the caller leaves them to us (what bench.py does by hand):
+    `slots` searches in flight on a state-page pool that would cover the worst case of slots / oversub of them (a
+    search holds only the pages it has filled), at most `cap` (the measured best at BJ scale),
+    in whole multiples of 1 024.  Returns (slots, pool_pages, ramp_steps); ramp_steps > 0 when the pool is below the
+    worst case, so that the first searches start spread over that many supersteps."""
+    budget = int(free_bytes * budget_frac) - out_bytes_per_od * n_od
+    per = fixed_per_slot + pages_per_search * page_bytes / oversub
+    slots = int(max(budget, 0) // per)
+    slots = min(slots, cap, max(n_od, 1))
+    if slots >= 1024:
+        slots = slots // 1024 * 1024
+    elif slots >= 128:
+        slots = slots // 128 * 128
+    slots = max(slots, 1)
+    pool = min(slots * pages_per_search, int(max(budget - slots * fixed_per_slot, 0) // page_bytes))
+    pool = max(pool, pages_per_search)
+    return slots, pool, (1500 if pool < slots * pages_per_search else 0)
+
+
+AUTO_PLAN_MIN_OD = 32768        # batches from this size on get plan_engine's sizes and two engines by default
+
+
 class Searcher(object):
     # 1: hidden states as split-f16 words, recurrence on the f16 matrix cores in three passes (fp32-grade
     # products, include/tsg.h tsg_engine.state_format); 0: plain fp32 states on the fp32 matrix-core path
@@ -43,6 +67,7 @@ class Searcher(object):
         self.road_time_distribution = road_time_distribution.astype(int)
         self._graph = None
         self._engines = {}
+        self._streams = []          # one per engine of a side-by-side run, kept for the Searcher's life
         self._label_key = None
 
     # -- device substrate ------------------------------------------------------------------------
@@ -51,6 +76,23 @@ class Searcher(object):
             self._graph = GraphTables(self.device, self.adjacent_list, self.road_center_gps, self.road_length,
                                       self.road_time_distribution)
         return self._graph
+
+    def _held_bytes(self):
+        total = 0
+        for val in self._engines.values():
+            for eng in (val if isinstance(val, list) else [val]):
+                for v in eng.__dict__.values():
+                    for x in (v if isinstance(v, list) else [v]):
+                        if torch.is_tensor(x) and x.is_cuda:
+                            total += x.numel() * x.element_size()
+        return total
+
+    def _drop_engines(self):
+        """Release the workspaces of every engine held (before a new set is allocated, or on request)."""
+        for val in self._engines.values():
+            for eng in (val if isinstance(val, list) else [val]):
+                eng.close()
+        self._engines.clear()
 
     def _engine(self, gen_model, slots, max_step, max_prefix, lmax, streams=1, pool_pages=None, admit_reserve=None,
                 ramp_steps=0, exact=True):
@@ -67,7 +109,7 @@ class Searcher(object):
                         cand.max_step >= max_step and cand.max_prefix >= max_prefix):
                     return cand
         if eng is None:
-            self._engines.clear()       # one engine's workspaces at a time
+            self._drop_engines()        # one engine's workspaces at a time
             eng = AStarEngine(tables, self.graph(), slots, max_step, max_prefix, lmax, streams,
                               state_format=self.state_format, pool_pages=pool_pages, admit_reserve=admit_reserve,
                               ramp_steps=ramp_steps)
@@ -118,7 +160,20 @@ class Searcher(object):
         ms_cap = int(ms.max()) if n_od else 1
         tables = gen_model.tables()
         auto = slots is None
-        if auto:
+        if auto and pool_pages is None and prefixes is None and n_od >= AUTO_PLAN_MIN_OD:
+            # a large plain batch with nothing said about sizes: the searches in flight, the shared page pool and
+            # the start ramp as the bench sizes them, two engines side by side unless the caller chose
+            free, _total = torch.cuda.mem_get_info(self.device)
+            free += max(0, torch.cuda.memory_reserved(self.device) - torch.cuda.memory_allocated(self.device))
+            free += self._held_bytes()      # what the engines of an earlier call hold is ours to use again
+            free = free >> 30 << 30         # whole GiB: the same plan, and with it the same engines, call after call
+            slots, pool_pages, ramp_steps = plan_engine(
+                free, AStarEngine.fixed_bytes_per_slot(self.graph(), ms_cap, max_prefix),
+                AStarEngine.bytes_per_page(tables), (max_prefix + ms_cap + 63) // 64, n_od, (2 * lmax + 8) * 4)
+            if streams is None:
+                streams = 2
+            auto = False
+        elif auto:
             slots = _auto_slots(tables, self.graph(), ms_cap, max_prefix, n_od, self.device)
         n_eng = max(1, int(streams or 1))
         dl = np.asarray(default_lens, dtype=np.int32)
@@ -179,10 +234,12 @@ class Searcher(object):
                reserve_each, ramp_steps)
         engines = self._engines.get(key)
         if engines is None:
-            self._engines.clear()
+            self._drop_engines()
+            while len(self._streams) < n_eng:
+                self._streams.append(torch.cuda.Stream(device=self.device))
             engines = [AStarEngine(tables, self.graph(), slots_each, ms_cap, max_prefix, lmax, 1,
                                    state_format=self.state_format, pool_pages=pool_each, admit_reserve=reserve_each,
-                                   ramp_steps=ramp_steps) for _ in range(n_eng)]
+                                   ramp_steps=ramp_steps, stream=self._streams[e]) for e in range(n_eng)]
             self._engines[key] = engines
         plen = np.diff(prefix_ptr).astype(np.int64)
         out, err = [None] * n_eng, [None] * n_eng
