@@ -51,6 +51,46 @@ def plan_engine(free_bytes, fixed_per_slot, page_bytes, pages_per_search, n_od, 
     return slots, pool, (1500 if pool < slots * pages_per_search else 0)
 
 
+def streams_apart(device, n, tries=16, spin_cycles=1_500_000):
+    """n streams that run side by side with each other and with the default stream.  Streams are bound to a few
+    hardware queues (four per process here) in an order the runtime chooses, and two streams on one queue do not
+    overlap: of eight new torch streams on an MI355X box, four pairs shared a queue, two of them with the default
+    stream (ablate/stream_queues.py).  Test: two spin kernels on two streams take the time of one when the
+    streams sit on different queues."""
+    import time
+    dev = torch.device(device)
+    if n <= 0:
+        return []
+    if not hasattr(torch.cuda, '_sleep'):
+        return [torch.cuda.Stream(device=dev) for _ in range(n)]
+    with torch.cuda.device(dev):
+        def spin(a, b=None):
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            with torch.cuda.stream(a):
+                torch.cuda._sleep(spin_cycles)
+            if b is not None:
+                with torch.cuda.stream(b):
+                    torch.cuda._sleep(spin_cycles)
+            torch.cuda.synchronize(dev)
+            return time.perf_counter() - t0
+        base = torch.cuda.default_stream(dev)
+        chosen, spare = [], []
+        first = torch.cuda.Stream(device=dev)
+        spin(first)
+        one = min(spin(first) for _ in range(3))
+        cand = first
+        for _ in range(tries):
+            if all(spin(cand, o) < 1.5 * one for o in chosen + [base]):
+                chosen.append(cand)
+                if len(chosen) == n:
+                    break
+            else:
+                spare.append(cand)
+            cand = torch.cuda.Stream(device=dev)
+        return (chosen + spare + [torch.cuda.Stream(device=dev) for _ in range(n)])[:n]
+
+
 AUTO_PLAN_MIN_OD = 32768        # batches from this size on get plan_engine's sizes and two engines by default
 
 
@@ -110,9 +150,11 @@ class Searcher(object):
                     return cand
         if eng is None:
             self._drop_engines()        # one engine's workspaces at a time
+            if not self._streams:
+                self._streams = streams_apart(self.device, 1)
             eng = AStarEngine(tables, self.graph(), slots, max_step, max_prefix, lmax, streams,
                               state_format=self.state_format, pool_pages=pool_pages, admit_reserve=admit_reserve,
-                              ramp_steps=ramp_steps)
+                              ramp_steps=ramp_steps, stream=self._streams[0])
             self._engines[key] = eng
         return eng
 
@@ -235,8 +277,8 @@ class Searcher(object):
         engines = self._engines.get(key)
         if engines is None:
             self._drop_engines()
-            while len(self._streams) < n_eng:
-                self._streams.append(torch.cuda.Stream(device=self.device))
+            if len(self._streams) < n_eng:        # no engine is left that holds one of the old ones
+                self._streams = streams_apart(self.device, n_eng)
             engines = [AStarEngine(tables, self.graph(), slots_each, ms_cap, max_prefix, lmax, 1,
                                    state_format=self.state_format, pool_pages=pool_each, admit_reserve=reserve_each,
                                    ramp_steps=ramp_steps, stream=self._streams[e]) for e in range(n_eng)]
@@ -431,6 +473,7 @@ class DoubleLayerSearcher(object):
             s._graph = GraphTables.for_regions(self.device, self.region_adjacent_list, self.region_dist,
                                                self.region_time_distribution, len(self.region2rid))
             s._engines = {}
+            s._streams = []
             s._label_key = None
             self._region_search = s
         return self._region_search
