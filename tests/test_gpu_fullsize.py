@@ -100,8 +100,8 @@ def test_config0_trajectories_match_oracle(grid, state_format):
                                     [int(od['start_time'][i])], int(od['des'][i]), int(od['default_len'][i]),
                                     max_step, stats=st)
         kinds.append(_same_or_near_tie(res, i, loc, tim, st))
-    exact, near = kinds.count('exact'), kinds.count('near-tie')
-    assert exact >= len(od['des']) - 2, (exact, near)
+    from tests._fixtures import report_near_ties
+    report_near_ties('config[0] at BJ dims against the oracle, state_format %d' % state_format, kinds, recorded=0)
 
 
 def _same_or_near_tie(res, i, loc, tim, st):
@@ -194,7 +194,8 @@ def test_config1_split_recurrence_against_fp32(porto):
         n, k = int(b['len'][i]), int(b['poplog_n'][i])
         kinds.append(classify_traj(a, i, b['rid'][i, :n].tolist(), b['time'][i, :n].tolist(),
                                    b['poplog_rid'][i, :k].tolist(), b['poplog_prio'][i, :k].tolist()))
-    assert kinds.count('exact') >= 512 - 5, kinds.count('near-tie')      # every other one is a proven near-tie
+    from tests._fixtures import report_near_ties
+    report_near_ties('config[1] split-f16 against fp32 recurrence (512 searches)', kinds, recorded=0)   # every other one is a proven near-tie
 
 
 def test_config1_state_page_pool_under_pressure(porto):
@@ -353,5 +354,6 @@ def test_config2_bj_scale_against_oracle(bj):
         s.state_format = fmt
         res = s.generate(model, od['start'][:n], od['start_time'][:n], od['des'][:n], od['default_len'][:n],
                          max_step=max_step, slots=8, poplog_cap=max_step + 8)
-        for i in range(n):
-            _same_or_near_tie(res, i, *want_tr[i])
+        kinds = [_same_or_near_tie(res, i, *want_tr[i]) for i in range(n)]
+        from tests._fixtures import report_near_ties
+        report_near_ties('config[2] BJ scale against the oracle, state_format %d' % fmt, kinds, recorded=0)

@@ -163,6 +163,26 @@ def test_border_orders_equal_randomstate_choice():
             assert np.array_equal(want, got), (i, k)
 
 
+def test_border_orders_rejects_what_numpy_rejects():
+    """A probability vector with a zero, a negative or a NaN entry, and a seed outside [0, 2^32): numpy's
+    RandomState.choice(replace=False, p) / RandomState(seed) raise ValueError; so does the C helper (its draw loop
+    would otherwise never end on such a vector)."""
+    from ts_trajgen_amd.search import border_orders
+    leg_ptr, leg_pair, pair_ptr = np.array([0, 1]), np.array([0], dtype=np.int32), np.array([0, 3])
+    for p in ([0.5, 0.0, 0.5], [0.7, -0.2, 0.5], [0.5, float('nan'), 0.5]):
+        with pytest.raises(ValueError):
+            np.random.RandomState(0).choice(3, 3, p=np.array(p), replace=False)
+        with pytest.raises(ValueError):
+            border_orders([0], leg_ptr, leg_pair, pair_ptr, np.array(p))
+    for seed in (-1, 2 ** 32):
+        with pytest.raises(ValueError):
+            np.random.RandomState(seed)
+        with pytest.raises(ValueError):
+            border_orders([seed], leg_ptr, leg_pair, pair_ptr, np.array([0.2, 0.3, 0.5]))
+    out_ptr, out_idx = border_orders([5], leg_ptr, leg_pair, pair_ptr, np.array([0.2, 0.3, 0.5]))
+    assert sorted(out_idx[:3].tolist()) == [0, 1, 2]
+
+
 class _QNode(object):
     """SearchNode's ordering (search.py:48-52): by the node's CURRENT log_prob."""
     def __init__(self, i, lp):

@@ -5,7 +5,7 @@ import torch
 
 from oracle import model as om
 from oracle import search as osr
-from tests._fixtures import GoldenRegionWorld, GoldenRoadWorld, load_json, load_npz
+from tests._fixtures import G11World, GoldenRegionWorld, GoldenRoadWorld, load_json, load_npz
 
 RTOL = 1e-5   # oracle vs reference: same torch-CPU fp32 ops, only the op grouping differs
 
@@ -136,6 +136,38 @@ def test_g5_astar(road):
         _check_search_case(loc, tim, st, c)
         kinds.add(st.status)
     assert kinds == {osr.REACHED, osr.FALLBACK, osr.UNTOUCHED}
+
+
+def test_g11_bj_dims_config0():
+    """The oracle at BJ model dims (hidden 256, 2-layer LSTM, GAT 5 x 256) against the REFERENCE's own run of
+    BASELINE.json configs[0] (golden G11: search.py:240-424 driving generator_v4.py:56-72 under max_step 5000):
+    trajectories, full pop order, priorities.  The reference took ~20 core-minutes for all 256 OD pairs; the CPU suite
+    takes the 24 shortest searches, the median one (1 113 pops) and the longest one (1 982 pops); the GPU test
+    (tests/test_gpu_g11.py) takes all 256."""
+    w = G11World()
+    model, cfg = w.model()
+    m = w.oracle_model(model, cfg)
+    rtd = w.net.road_time_distribution.astype(int)
+    order = np.argsort(w.z['npop'], kind='stable')
+    picked = [int(i) for i in order[:24]] + [int(order[128]), int(order[-1])]
+    threads = torch.get_num_threads()
+    torch.set_num_threads(1)          # batch-1 model calls: more threads only add synchronisation
+    try:
+        _g11_check(w, m, rtd, picked)
+    finally:
+        torch.set_num_threads(threads)
+
+
+def _g11_check(w, m, rtd, picked):
+    for i in picked:
+        c = w.case(i)
+        st = osr.SearchStats()
+        loc, tim = osr.astar_search(m, w.net.adjacent_list, w.net.rid_gps, w.net.road_length, rtd,
+                                    [int(w.od['start'][i])], [int(w.od['start_time'][i])], int(w.od['des'][i]),
+                                    int(w.od['default_len'][i]), w.MAX_STEP, stats=st)
+        assert loc == c['loc'] and tim == c['tim'], i
+        assert [p[0] for p in st.pops] == c['pop_rid'], i
+        np.testing.assert_allclose([p[1] for p in st.pops], c['pop_prio'], rtol=1e-5, atol=1e-6)
 
 
 def test_g6_astar_in_region(road, region):

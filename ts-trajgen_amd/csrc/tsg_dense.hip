@@ -20,7 +20,7 @@
 #define BK 32
 #define A_LD 33
 
-struct TileLds {
+struct alignas(16) TileLds {  // b rows are written as float4 (ds_write_b128): 16-byte aligned by construction
   float a[BM][A_LD];
   float b[BK][BN];
 };

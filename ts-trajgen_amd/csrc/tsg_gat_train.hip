@@ -168,9 +168,11 @@ __global__ __launch_bounds__(256) void gt_bwd_target_kernel(tsg_gat_train d) {
   }
   const float st = d.s_trg[(size_t)w];
   float ds_t = 0.0f;
+  // lane 0's stores above are read back by all lanes below: the fence orders them (release at agent scope: the
+  // stores have reached the L2 before any load that follows is issued), the loads go past the vector L1
+  __threadfence();
   for (int j = j0 + lane; j < j1; j += 64) {
     const float att = d.att[(size_t)j * nh + h];
-    // (read back past the vector L1: lane 0 of this wave wrote it a moment ago)
     const float datt = __hip_atomic_load(&d.d_pre[(size_t)j * nh + h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const float de = att * (datt - dot);                                 // softmax over the neighbourhood
     const float pre = d.s_src[(size_t)d.in_src[j] * nh + h] + st;

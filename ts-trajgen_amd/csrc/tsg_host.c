@@ -61,7 +61,10 @@ static double mt_double(mt_state* s) {
 /* n_od OD pairs; OD i draws, from RandomState(seed[i]), one order per leg od_ptr[i] <= l < od_ptr[i+1]; leg l uses
  * the probability vector of pair leg_pair[l]: pair_p[pair_ptr[q] .. pair_ptr[q+1]) (already normalised by the
  * caller, as the reference passes it).  The order of leg l (indices into its pair's list) goes to
- * out_idx[out_ptr[l] .. out_ptr[l] + size).  Returns 0, or -1 on bad arguments / allocation failure. */
+ * out_idx[out_ptr[l] .. out_ptr[l] + size).  Returns 0; -1 on bad arguments / allocation failure; -2 when a pair's
+ * probability vector has fewer positive entries than its list has roads, or an entry that is negative or not a number
+ * (numpy raises ValueError there: 'Fewer non-zero entries in p than size' / 'probabilities are not non-negative';
+ * the draw loop below would otherwise never end). */
 int tsg_host_border_orders(int32_t n_od, const uint32_t* seed, const int64_t* od_ptr, const int32_t* leg_pair,
                            const int64_t* pair_ptr, const double* pair_p, const int64_t* out_ptr, int32_t* out_idx,
                            int32_t max_size) {
@@ -91,6 +94,16 @@ int tsg_host_border_orders(int32_t n_od, const uint32_t* seed, const int64_t* od
       for (int k = 0; k < size; ++k) {
         p[k] = pp[k];
         seen[k] = 0;
+      }
+      int n_pos = 0, bad = 0;
+      for (int k = 0; k < size; ++k) {
+        if (!(pp[k] >= 0.0)) bad = 1; /* negative or NaN */
+        if (pp[k] > 0.0) ++n_pos;
+      }
+      if (bad || n_pos < size) {
+        free(p);
+        free(seen);
+        return -2;
       }
       int n_found = 0;
       while (n_found < size) {

@@ -18,11 +18,12 @@ STATUS_UNTOUCHED, STATUS_REACHED, STATUS_FALLBACK = (_lib.STATUS_UNTOUCHED, _lib
                                                      _lib.STATUS_FALLBACK)
 
 
-def _auto_slots(tables, graph, max_step, max_prefix, n_od, device, budget_frac=0.6, cap=8192):
+def _auto_slots(tables, graph, max_step, max_prefix, n_od, device, budget_frac=0.6, cap=8192, held=0):
     per = AStarEngine.bytes_per_slot(tables, graph, max_step, max_prefix)
     free, _total = torch.cuda.mem_get_info(device)
-    # what torch's caching allocator holds without using it is as available to the engine as the driver's free memory
-    free += max(0, torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device))
+    # what torch's caching allocator holds without using it is as available to the engine as the driver's free memory,
+    # and so is what the Searcher's own engines hold (`held`): they are released before a new one is allocated
+    free += max(0, torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device)) + int(held)
     fit = max(1, int(free * budget_frac) // per)
     slots = min(cap, fit, max(n_od, 1))
     if slots >= 128:
@@ -51,14 +52,21 @@ def plan_engine(free_bytes, fixed_per_slot, page_bytes, pages_per_search, n_od, 
     return slots, pool, (1500 if pool < slots * pages_per_search else 0)
 
 
-def streams_apart(device, n, tries=16, spin_cycles=1_500_000):
+def streams_apart(device, n, tries=16, spin_cycles=1_500_000, report=None):
     """n streams that run side by side with each other and with the default stream.  Streams are bound to a few
     hardware queues (four per process here) in an order the runtime chooses, and two streams on one queue do not
     overlap: of eight new torch streams on an MI355X box, four pairs shared a queue, two of them with the default
     stream (ablate/stream_queues.py).  Test: two spin kernels on two streams take the time of one when the
-    streams sit on different queues."""
+    streams sit on different queues (the minimum of three spins per pair: a busy host can only lengthen a spin).
+    `report` (a dict) receives 'queues_apart': True when all n streams passed the test against each other and the
+    default stream, False when the list had to be padded with untested streams (a pair of engines on streams that
+    share a queue does not overlap: 15.5 k instead of 21.6 k trajectories/s at BJ scale), None when the test
+    could not be run."""
     import time
     dev = torch.device(device)
+    if report is None:
+        report = {}
+    report['queues_apart'] = None
     if n <= 0:
         return []
     if not hasattr(torch.cuda, '_sleep'):
@@ -81,13 +89,14 @@ def streams_apart(device, n, tries=16, spin_cycles=1_500_000):
         one = min(spin(first) for _ in range(3))
         cand = first
         for _ in range(tries):
-            if all(spin(cand, o) < 1.5 * one for o in chosen + [base]):
+            if all(min(spin(cand, o) for _ in range(3)) < 1.5 * one for o in chosen + [base]):
                 chosen.append(cand)
                 if len(chosen) == n:
                     break
             else:
                 spare.append(cand)
             cand = torch.cuda.Stream(device=dev)
+        report['queues_apart'] = len(chosen) == n
         return (chosen + spare + [torch.cuda.Stream(device=dev) for _ in range(n)])[:n]
 
 
@@ -108,6 +117,15 @@ class Searcher(object):
         self._graph = None
         self._engines = {}
         self._streams = []          # one per engine of a side-by-side run, kept for the Searcher's life
+        self._stream_report = {}    # streams_apart's verdict on them ('queues_apart'), copied into last_stats
+        # Memory policy of generate() when the caller gives no sizes: the share of the device memory that is free
+        # (driver-free + torch's cached-but-unused blocks + what this Searcher's own engines hold) an engine may
+        # take.  Large plain batches (>= AUTO_PLAN_MIN_OD pairs) are planned against `plan_budget_frac`, everything
+        # else against `budget_frac`.  A caller that allocates afterwards (a training loop, a second model) lowers
+        # them, or passes slots / pool_pages itself, or sets auto_plan = False.
+        self.budget_frac = 0.6
+        self.plan_budget_frac = 0.93
+        self.auto_plan = True
         self._label_key = None
 
     # -- device substrate ------------------------------------------------------------------------
@@ -151,7 +169,7 @@ class Searcher(object):
         if eng is None:
             self._drop_engines()        # one engine's workspaces at a time
             if not self._streams:
-                self._streams = streams_apart(self.device, 1)
+                self._streams = streams_apart(self.device, 1, report=self._stream_report)
             eng = AStarEngine(tables, self.graph(), slots, max_step, max_prefix, lmax, streams,
                               state_format=self.state_format, pool_pages=pool_pages, admit_reserve=admit_reserve,
                               ramp_steps=ramp_steps, stream=self._streams[0])
@@ -202,7 +220,7 @@ class Searcher(object):
         ms_cap = int(ms.max()) if n_od else 1
         tables = gen_model.tables()
         auto = slots is None
-        if auto and pool_pages is None and prefixes is None and n_od >= AUTO_PLAN_MIN_OD:
+        if auto and self.auto_plan and pool_pages is None and prefixes is None and n_od >= AUTO_PLAN_MIN_OD:
             # a large plain batch with nothing said about sizes: the searches in flight, the shared page pool and
             # the start ramp as the bench sizes them, two engines side by side unless the caller chose
             free, _total = torch.cuda.mem_get_info(self.device)
@@ -211,12 +229,14 @@ class Searcher(object):
             free = free >> 30 << 30         # whole GiB: the same plan, and with it the same engines, call after call
             slots, pool_pages, ramp_steps = plan_engine(
                 free, AStarEngine.fixed_bytes_per_slot(self.graph(), ms_cap, max_prefix),
-                AStarEngine.bytes_per_page(tables), (max_prefix + ms_cap + 63) // 64, n_od, (2 * lmax + 8) * 4)
+                AStarEngine.bytes_per_page(tables), (max_prefix + ms_cap + 63) // 64, n_od, (2 * lmax + 8) * 4,
+                budget_frac=self.plan_budget_frac)
             if streams is None:
                 streams = 2
             auto = False
         elif auto:
-            slots = _auto_slots(tables, self.graph(), ms_cap, max_prefix, n_od, self.device)
+            slots = _auto_slots(tables, self.graph(), ms_cap, max_prefix, n_od, self.device,
+                                budget_frac=self.budget_frac, held=self._held_bytes())
         n_eng = max(1, int(streams or 1))
         dl = np.asarray(default_lens, dtype=np.int32)
         al = None if allow_label is None else np.broadcast_to(np.asarray(allow_label, dtype=np.int32), (n_od,))
@@ -228,6 +248,7 @@ class Searcher(object):
         eng = self._engine(gen_model, int(slots), ms_cap, max_prefix, lmax, 1, pool_pages, admit_reserve,
                            ramp_steps, exact=not auto)
         res, self.last_stats = self._run_engine(eng, prefix_ptr, prefix_rid, prefix_time, des, dl, ms, al, run_kw)
+        self.last_stats = dict(self.last_stats, engines=1, queues_apart=self._stream_report.get('queues_apart'))
         return res
 
     @staticmethod
@@ -278,7 +299,7 @@ class Searcher(object):
         if engines is None:
             self._drop_engines()
             if len(self._streams) < n_eng:        # no engine is left that holds one of the old ones
-                self._streams = streams_apart(self.device, n_eng)
+                self._streams = streams_apart(self.device, n_eng, report=self._stream_report)
             engines = [AStarEngine(tables, self.graph(), slots_each, ms_cap, max_prefix, lmax, 1,
                                    state_format=self.state_format, pool_pages=pool_each, admit_reserve=reserve_each,
                                    ramp_steps=ramp_steps, stream=self._streams[e]) for e in range(n_eng)]
@@ -319,6 +340,7 @@ class Searcher(object):
         self.last_stats = self._merge_stats([o[1] for o in out])
         self.last_stats['supersteps'] = max(o[1]['supersteps'] for o in out)
         self.last_stats['engines'] = n_eng
+        self.last_stats['queues_apart'] = self._stream_report.get('queues_apart')
         return res
 
     # -- reference API (one OD per call) ---------------------------------------------------------
@@ -415,7 +437,10 @@ def border_orders(seeds, leg_ptr, leg_pair, pair_ptr, pair_p):
     element what ordered_draw / RandomState.choice(replace=False, p=...) return (tests/test_host.py).  Runs in
     libtsg_host.so (plain C): seeding 10^5 generators and drawing in Python was the bottleneck of the two-stage path."""
     H = _lib.host_lib()
-    seeds = np.ascontiguousarray(np.asarray(seeds, dtype=np.int64) & 0xFFFFFFFF, dtype=np.uint32)
+    seeds = np.asarray(seeds, dtype=np.int64)
+    if len(seeds) and (int(seeds.min()) < 0 or int(seeds.max()) > 0xFFFFFFFF):
+        raise ValueError('Seed must be between 0 and 2**32 - 1')      # as numpy.random.RandomState(seed)
+    seeds = np.ascontiguousarray(seeds, dtype=np.uint32)
     leg_ptr = np.ascontiguousarray(leg_ptr, dtype=np.int64)
     leg_pair = np.ascontiguousarray(leg_pair, dtype=np.int32)
     pair_ptr = np.ascontiguousarray(pair_ptr, dtype=np.int64)
@@ -430,6 +455,9 @@ def border_orders(seeds, leg_ptr, leg_pair, pair_ptr, pair_p):
         return a.ctypes.data_as(C.c_void_p)
     rc = H.tsg_host_border_orders(len(seeds), ptr(seeds), ptr(leg_ptr), ptr(leg_pair), ptr(pair_ptr), ptr(pair_p),
                                   ptr(out_ptr), ptr(out_idx), max(1, max_size))
+    if rc == -2:      # numpy's choice(replace=False, p) raises the same way
+        raise ValueError('a border-road probability vector has fewer positive entries than roads, or a negative / '
+                         'NaN entry (numpy: "Fewer non-zero entries in p than size")')
     if rc != 0:
         raise RuntimeError('tsg_host_border_orders failed (%d)' % rc)
     return out_ptr, out_idx
