@@ -61,14 +61,18 @@ def parse():
     ap.add_argument('--profile-every', type=int, default=8, help='event-bracket every k-th chunk of supersteps')
     ap.add_argument('--lstm', default='split', choices=['split', 'fp32'],
                     help='recurrent matmul: split-f16 three-pass matrix-core form (fp32-grade products) or plain fp32 MFMA')
-    ap.add_argument('--cpu-seconds', type=float, default=25.0,
-                    help='CPU baseline: no new OD pair is started after this many seconds (0 = skip)')
-    ap.add_argument('--cpu-ods', type=int, default=64, help='CPU baseline: the fixed sample = first k OD pairs')
+    ap.add_argument('--cpu-seconds', type=float, default=10.0,
+                    help='CPU baseline: length of a timed pass in seconds (0 = skip)')
+    ap.add_argument('--cpu-passes', type=int, default=3, help='CPU baseline: timed passes over the sample (the median counts)')
+    ap.add_argument('--cpu-ods', type=int, default=32, help='CPU baseline: the fixed sample = first k OD pairs')
     ap.add_argument('--engines', type=int, default=1,
                     help='independent engines side by side in the timed step (Searcher.generate streams=E); the '
                          'default line keeps one, so that its per-kernel times are those of undisturbed launches')
     ap.add_argument('--two-engines', type=int, default=1,
                     help='N = 1: also time one step of the same workload on two engines (sub-record; 0 = skip)')
+    ap.add_argument('--fp32-step', type=int, default=1,
+                    help='N = 1, --lstm split: also time one step of the same workload with the strict-fp32 recurrence '
+                         '(state_format 0) and compare its trajectories with the split-f16 step (sub-record; 0 = skip)')
     ap.add_argument('--two-stage-ods', type=int, default=16384,
                     help='OD pairs of the two-stage sub-record (configs[3], N = 1 only; 0 = skip)')
     return ap.parse_args()
@@ -174,7 +178,10 @@ def gat_encoder_timing(model, net, cfg, reps=5):
         # gathered per edge, the [N][(NH+1)FIN] operand written and read once, the stacked weights, the output
         moved = 8.0 * n * fin + 8.0 * n * nh + e * (8.0 * nh + 4.0 * fin + 4) + 8.0 * n * kw + 4.0 * kw * f + 4.0 * n * f
         out.update({'form': 'input-space (projection not materialised)', 'moved_bytes': moved,
-                    'moved_GBs': moved / (ms * 1e-3) / 1e9})
+                    'moved_GBs': moved / (ms * 1e-3) / 1e9,
+                    # `frac` prices SURVEY 8(d)'s unit of work (the materialised form's bytes) and is NOT an HBM
+                    # efficiency: this form moves `moved_bytes`; against those the encoder runs at frac_of_moved
+                    'frac_of_moved': moved / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS})
     return out
 
 
@@ -225,16 +232,26 @@ def _cpu_worker_init():
                      int(o['od']['default_len'][0]), 30)
 
 
-def _cpu_worker(i):
+def _cpu_worker_window(arg):
+    """One worker, one pass: searches of the fixed sample (worker k starts at OD pair k and strides by the number of
+    workers, wrapping around) until the pass's deadline; a search cut short by the deadline counts the expansions it
+    made.  Returns (expansions, searches finished)."""
     from oracle import search as osr
+    k, n_workers, t_end = arg
     o = _CPU
-    if time.time() - o['t0'] > o['budget']:
-        return None
-    st = osr.SearchStats()
-    osr.astar_search(o['om'], o['net'].adjacent_list, o['net'].rid_gps, o['net'].road_length, o['rtd'],
-                     [int(o['od']['start'][i])], [int(o['od']['start_time'][i])], int(o['od']['des'][i]),
-                     int(o['od']['default_len'][i]), o['max_step'], stats=st)
-    return st.steps
+    n = o['n_sample']
+    steps = finished = 0
+    i = k % n
+    while time.time() < t_end:
+        st = osr.SearchStats()
+        st.deadline = t_end
+        osr.astar_search(o['om'], o['net'].adjacent_list, o['net'].rid_gps, o['net'].road_length, o['rtd'],
+                         [int(o['od']['start'][i])], [int(o['od']['start_time'][i])], int(o['od']['des'][i]),
+                         int(o['od']['default_len'][i]), o['max_step'], stats=st)
+        steps += st.steps
+        finished += int(time.time() < t_end)
+        i = (i + n_workers) % n
+    return steps, finished
 
 
 def cpu_model_name():
@@ -248,13 +265,17 @@ def cpu_model_name():
     return 'unknown'
 
 
-def cpu_baseline(net, model, cfg, od, budget_s, max_step, n_sample):
+def cpu_baseline(net, model, cfg, od, window_s, max_step, n_sample, passes=3):
     """The CPU oracle (port of search.py:240-424 + generator_v4.py:56-72: the reference's algorithm, one OD pair at a
     time, the LSTM re-run over the whole prefix at every expansion) on a FIXED sample: the first `n_sample` OD pairs
     of the workload, same max_step, one search per host core (forked workers, torch at one thread each: the
     reference's batch-1 model call does not use more), after one warm-up search per worker.  Runs before this
-    process touches the GPU (the workers are forks).  No new OD pair is started after `budget_s` seconds, so the
-    default bench finishes in minutes whatever the host; the sample actually completed is reported."""
+    process touches the GPU (the workers are forks).  SURVEY 8(d): one warm-up, then `passes` timed passes, the MEDIAN
+    counts.  A search of this workload takes a core 15-25 s, so a pass is a fixed window of `window_s` seconds in which
+    every core runs searches of the sample and the EXPANSIONS completed are counted (the data-independent unit;
+    a search cut short by the end of the window counts what it did): the bench finishes in minutes whatever the
+    host.  main() turns the median expansions/s into trajectories/s with the workload's mean expansions per OD pair
+    (the GPU run of the same searches counts the same expansions: `step` of search.py:420)."""
     import multiprocessing as mp
     import torch
     from oracle.model import OracleGenerator
@@ -270,24 +291,29 @@ def cpu_baseline(net, model, cfg, od, budget_s, max_step, n_sample):
     om.setup_node_emb()
     n_sample = min(n_sample, len(od['des']))
     _CPU.update({'om': om, 'net': net, 'rtd': net.road_time_distribution.astype(int), 'od': od,
-                 'max_step': max_step, 'budget': budget_s, 't0': 0.0})
+                 'max_step': max_step, 'n_sample': n_sample})
+    runs = []
     with mp.get_context('fork').Pool(workers, initializer=_cpu_worker_init) as pool:
         pool.map(_cpu_noop, range(workers * 4))          # every worker is up and warm before the clock starts
-        t0 = time.time()
-        # the budget is checked in the workers against the parent's clock: fork copies _CPU, so the start time
-        # travels with every task instead
-        res = pool.map(_cpu_worker_timed, [(i, t0) for i in range(n_sample)], chunksize=1)
-        dt = time.time() - t0
+        for _ in range(max(1, passes)):
+            t0 = time.time()
+            res = pool.map(_cpu_worker_window, [(k, workers, t0 + window_s) for k in range(workers)], chunksize=1)
+            dt = time.time() - t0
+            runs.append((sum(r[0] for r in res) / dt, int(sum(r[0] for r in res)), int(sum(r[1] for r in res)), dt))
     torch.set_num_threads(prev_threads)
     _CPU.clear()
-    done = [r for r in res if r is not None]
-    steps = int(sum(done))
-    return {'value': len(done) / dt, 'unit': 'trajectories/s', 'cores': workers, 'kind': 'port',
-            'sample': 'first %d OD pairs of the same workload (fixed sample of %d; %d expansions) in %.1f s: one '
-                      'search per core on %d forked workers, torch-CPU fp32 at 1 thread each, 1 warm-up search per '
-                      'worker, max_step %d' % (len(done), n_sample, steps, dt, workers, max_step),
-            'cpu_model': cpu_model_name(), 'host_cpus': os.cpu_count(), 'torch_threads_per_worker': 1,
-            'expansions_per_s': steps / dt}
+    runs.sort()
+    rate, steps, finished, dt = runs[len(runs) // 2]          # the median pass
+    return {'value': None, 'unit': 'trajectories/s', 'cores': workers, 'kind': 'port',
+            'expansions_per_s': rate,
+            'sample': 'median of %d passes of %.0f s: in a pass each of %d cores (forked workers, torch-CPU fp32 at 1 '
+                      'thread each, 1 warm-up search per worker) runs searches of the fixed sample (first %d OD pairs '
+                      'of the same workload, max_step %d) until the window ends; the median pass made %d expansions '
+                      'in %.1f s (%d searches ran to their end)'
+                      % (len(runs), window_s, workers, n_sample, max_step, steps, dt, finished),
+            'passes': [{'expansions_per_s': r[0], 'expansions': r[1], 'searches_finished': r[2], 'seconds': r[3]}
+                       for r in runs],
+            'cpu_model': cpu_model_name(), 'host_cpus': os.cpu_count(), 'torch_threads_per_worker': 1}
 
 
 def _cpu_noop(_):
@@ -295,10 +321,42 @@ def _cpu_noop(_):
     return 0
 
 
-def _cpu_worker_timed(arg):
-    i, t0 = arg
-    _CPU['t0'] = t0
-    return _cpu_worker(i)
+def classify_differences(searcher, model, od, idx, max_step, lmax, formats=(1, 0), tol=1e-5):
+    """OD pairs whose trajectories differ between the two recurrence forms: run them again under both with the pop
+    log on and find the first pop at which the two searches part.  'near_ties': the priorities of that pop agree
+    within `tol` relative (the documented exception of the north star: two candidates nearly equally likely, the
+    last bits decide); 'unexplained': anything else."""
+    import torch
+    runs = []
+    keep = searcher.state_format
+    for fmt in formats:
+        searcher._drop_engines()
+        searcher.state_format = fmt
+        runs.append(searcher.generate(model, od['start'][idx], od['start_time'][idx], od['des'][idx],
+                                      od['default_len'][idx], max_step=max_step, slots=min(1024, max(8, len(idx))),
+                                      lmax=lmax, poplog_cap=max_step + 8))
+    searcher._drop_engines()
+    searcher.state_format = keep
+    a, b = runs
+    near = unexplained = vanished = 0
+    for i in range(len(idx)):
+        if all(torch.equal(a[k][i], b[k][i]) for k in ('rid', 'time', 'len', 'status')):
+            vanished += 1          # cannot happen (results do not depend on the batch); counted to be sure
+            continue
+        ka, kb = int(a['poplog_n'][i]), int(b['poplog_n'][i])
+        ra, rb = a['poplog_rid'][i, :ka].numpy(), b['poplog_rid'][i, :kb].numpy()
+        m = min(ka, kb)
+        diff = np.flatnonzero(ra[:m] != rb[:m])
+        if len(diff) == 0:
+            unexplained += 1
+            continue
+        j = int(diff[0])
+        pa, pb = float(a['poplog_prio'][i, j]), float(b['poplog_prio'][i, j])
+        if abs(pa - pb) < tol * max(1.0, abs(pb)):
+            near += 1
+        else:
+            unexplained += 1
+    return {'near_ties': near, 'unexplained': unexplained, 'same_on_rerun': vanished}
 
 
 def two_stage_record(net, od, device, max_step):
@@ -361,8 +419,13 @@ def main():
         per_gpu = args.ods if args.ods > 0 else (131072 if args.config == 'bj' else 256 if args.config == 'grid' else 65536)
         n_total = per_gpu * world
     # OD pairs for all ranks (seeded), sharded round-robin by index; BFS default_len before the GPU is touched
-    od = synth.make_od_pairs(net, n_total, seed=2, workers=max(1, min(16, (os.cpu_count() or 1) // world)),
+    # (tsg_host_hop_distance: `setup_workers` pthreads; 131 072 OD pairs at BJ scale take 36 s on 2 threads of the
+    # build container, 9 s on 8)
+    setup_workers = max(1, min(16, (os.cpu_count() or 1) // world))
+    t_setup = time.time()
+    od = synth.make_od_pairs(net, n_total, seed=2, workers=setup_workers,
                              default_len='lattice' if args.config == 'stress' else 'hops', shard=(rank, world))
+    t_setup = time.time() - t_setup
     n_local = len(od['des'])
     od_warm = {k: v[:args.warmup_ods] for k, v in od.items()}
     net2 = od2 = None
@@ -373,7 +436,7 @@ def main():
     model, cfg = build_model_cpu(net, gat_dim=128 if args.config == 'stress' else None)
     cpu = None
     if world == 1 and args.cpu_seconds > 0:       # forks its workers: must come before the GPU is touched
-        cpu = cpu_baseline(net, model, cfg, od, args.cpu_seconds, args.max_step, args.cpu_ods)
+        cpu = cpu_baseline(net, model, cfg, od, args.cpu_seconds, args.max_step, args.cpu_ods, args.cpu_passes)
 
     import torch
     import torch.distributed as dist
@@ -388,6 +451,13 @@ def main():
             dist.init_process_group('nccl', device_id=torch.device(device))
         else:
             dist.init_process_group(backend)
+        # first contact with the communicator BEFORE the free memory is read and the page pool sized: RCCL creates its
+        # channels and workspaces at the first collective of each kind
+        warm = torch.zeros((world, 1 << 16), dtype=torch.int32, device=device)
+        dist.all_reduce(warm[0])
+        dist.all_gather_into_tensor(warm, warm[rank].clone())
+        torch.cuda.synchronize()
+        del warm
     from ts_trajgen_amd.search import Searcher
     model = to_device(model, cfg, device)
     searcher = Searcher(device, net.adjacent_list, net.rid_gps, net.road_length, net.road_time_distribution)
@@ -401,8 +471,14 @@ def main():
     pps = (1 + args.max_step + 63) // 64
     free_b, _total = torch.cuda.mem_get_info(torch.device(device))
     budget = int(free_b * 0.93) - (2 * args.lmax + 8) * 4 * n_local
+    rccl_headroom = 0
     if world > 1:
-        budget -= (2 * args.lmax + 8) * 4 * n_local * (world + 1)      # the packed rows and the gathered result
+        # the exchange step's buffers (rows trimmed to the longest trajectory; priced here at half of lmax, far above
+        # what the synthetic graphs produce) and an explicit reserve for RCCL's own channels and workspaces, which
+        # it allocates at the first collective, after the page pool has been sized
+        from ts_trajgen_amd.distributed import gather_plan_bytes
+        rccl_headroom = 4 << 30
+        budget -= gather_plan_bytes(n_total, world, args.lmax, width=args.lmax // 2) + rccl_headroom
     slots = args.slots
     if slots <= 0:
         slots = int(budget // (fixed + pps * page / args.oversub))
@@ -418,9 +494,9 @@ def main():
                                 profile_every=profile_every, pool_pages=pool_pages, ramp_steps=ramp,
                                 streams=args.engines)
         if world > 1:   # the single exchange step of the path: collect the padded trajectories (RCCL over xGMI)
-            from ts_trajgen_amd.distributed import gather_results, pack_rows
+            from ts_trajgen_amd.distributed import gather_results
             n_call = n_total if o is od else len(o['des']) * world
-            res['gathered'] = gather_results(pack_rows(res, args.lmax), n_call, args.lmax, rank, world)
+            res['gathered'] = gather_results(res, n_call, args.lmax, rank, world)
         return res
 
     def sync():
@@ -538,12 +614,47 @@ def main():
             dual = {'value': n_local / dt2, 'unit': 'trajectories/s', 'engines': 2, 'seconds': dt2,
                     'searches_in_flight_per_engine': slots // 2 // 128 * 128, 'supersteps': st2['supersteps'],
                     'page_waits': st2['page_waits'], 'restarts': st2['restarts'],
+                    'queues_apart': st2.get('queues_apart'),      # the two engines' streams passed the overlap test
                     'identical_to_single_engine': bool(all(torch.equal(res[k], res2[k])
                                                            for k in ('rid', 'time', 'len', 'status', 'steps'))),
                     'note': 'same workload and sizes as the timed step; latency-bound launches of one engine run '
                             'under the matrix-core / bandwidth-bound launches of the other (bench.py --engines 2 makes '
                             'it the timed step)'}
             del res2
+        fp32 = None
+        if world == 1 and args.fp32_step and args.lstm == 'split' and args.engines == 1 and n_local >= 8:
+            # the reference's recurrence is fp32 (function_g_fc.py:169); the timed step carries its operands as two
+            # f16 numbers (22 bits).  The same step on the plain fp32 matrix-core path (state_format 0), with the
+            # same sizes: whole-job throughput, per-kernel times, and its trajectories against the split-f16 step's
+            searcher._drop_engines()
+            searcher.state_format = 0
+            kw32 = dict(max_step=args.max_step, slots=slots, lmax=args.lmax, return_device=True,
+                        pool_pages=pool_pages, ramp_steps=ramp, streams=1)
+            searcher.generate(model, od_warm['start'], od_warm['start_time'], od_warm['des'], od_warm['default_len'], **kw32)
+            torch.cuda.synchronize()
+            t1 = time.time()
+            res32 = searcher.generate(model, od['start'], od['start_time'], od['des'], od['default_len'],
+                                      profile_every=args.profile_every, **kw32)
+            torch.cuda.synchronize()
+            dt32 = time.time() - t1
+            st32 = dict(searcher.last_stats)
+            same = torch.ones(n_local, dtype=torch.bool, device=res['len'].device)
+            for k in ('rid', 'time'):
+                same &= (res[k] == res32[k]).all(dim=1)
+            for k in ('len', 'status', 'steps'):
+                same &= res[k] == res32[k]
+            differ = torch.nonzero(~same).flatten().cpu().numpy()
+            del res32
+            searcher.state_format = 1
+            fp32 = {'value': n_local / dt32, 'unit': 'trajectories/s', 'seconds': dt32,
+                    'recurrence': 'fp32 matrix cores (v_mfma_f32_32x32x2_f32), hidden states stored as fp32',
+                    'vs_split_f16': (n_local / dt32) / (n_done / dt), 'supersteps': st32['supersteps'],
+                    'kernel_avg_us': {nm: (1e3 * st32['prof_ms'][i] / st32['prof_launches'][i]
+                                           if st32['prof_launches'][i] else None) for i, nm in enumerate(names)},
+                    'identical_to_split': int(n_local - len(differ)), 'od_pairs': int(n_local),
+                    'differing': int(len(differ))}
+            if 0 < len(differ) <= 4096:
+                fp32.update(classify_differences(searcher, model, od, differ, args.max_step, args.lmax))
         two = None
         if world == 1 and args.two_stage_ods > 0:
             del res
@@ -563,6 +674,10 @@ def main():
         recurrence = ('split-f16 x3: every fp32 operand as f16 major + f16 minor (22 significant bits), three f16 '
                       'matrix-core passes, fp32 accumulation; hidden states stored in that form, cell states fp32'
                       if args.lstm == 'split' else 'fp32 matrix cores (v_mfma_f32_32x32x2_f32)')
+        if cpu is not None:      # expansions/s -> trajectories/s with this workload's mean expansions per OD pair
+            per_od = exp_all / n_done
+            cpu['value'] = cpu['expansions_per_s'] / per_od
+            cpu['sample'] += '; trajectories/s = expansions/s / %.0f expansions per OD pair of this workload' % per_od
         out = {
             'metric': 'generated trajectories/sec (road-level A*)', 'value': n_done / dt, 'unit': 'trajectories/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt * 1e3 / args.steps,
@@ -575,7 +690,8 @@ def main():
                        'baseline_config': {'bj': 'configs[2]', 'porto': 'configs[1]', 'grid': 'configs[0]',
                                            'stress': 'configs[4]'}[args.config],
                        'od_pairs_per_step': n_total, 'od_pairs_per_gpu': n_local, 'slots_in_flight': slots,
-                       'engines': args.engines,
+                       'warmup_od_pairs': int(len(od_warm['des'])),      # a warm-up step is this many OD pairs per GPU, not a full step
+                       'engines': args.engines, 'queues_apart': stats[-1].get('queues_apart'),
                        'state_pool_pages': pool_pages, 'state_pool_gb': pool_pages * page / 1e9, 'lstm': args.lstm,
                        'recurrence': recurrence, 'parallelism': 'od-shard x%d' % world},
             'expansions_per_s': exp_all / dt, 'expansions_per_od': exp_all / n_done,
@@ -589,7 +705,9 @@ def main():
             'page_waits': int(sum(s['page_waits'] for s in stats)), 'restarts': int(sum(s['restarts'] for s in stats)),
             'min_free_pages': int(min(s['min_free_pages'] for s in stats)),
             'roofline': roofline, 'kernels': kern, 'measured_peaks': peaks, 'gat_encoder': gat, 'cpu_baseline': cpu, 'two_engines': dual,
-            'two_stage': two,
+            'fp32_recurrence': fp32, 'two_stage': two,
+            'setup': {'od_pairs_s': t_setup, 'workers': setup_workers, 'rccl_headroom_bytes': rccl_headroom,
+                      'note': 'hop distances (default_len) of this rank\'s OD pairs before the GPU is touched'},
         }
         print(json.dumps(out))
     if world > 1:

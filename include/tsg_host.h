@@ -24,10 +24,19 @@ extern "C" {
  * probability vector of region pair q = leg_pair[l]: pair_p[pair_ptr[q] .. pair_ptr[q+1]), already normalised by
  * the caller as the reference passes it.  The drawn order of leg l (indices into its pair's list) is written to
  * out_idx[out_ptr[l] .. out_ptr[l] + size_l), size_l = pair_ptr[q+1] - pair_ptr[q] <= max_size.
- * Returns 0, or -1 on bad arguments or when the scratch of 25 * max_size bytes cannot be allocated. */
+ * Returns 0; -1 on bad arguments or when the scratch of 25 * max_size bytes cannot be allocated; -2 when a
+ * probability vector has fewer positive entries than roads or a negative / NaN entry (numpy raises ValueError). */
 int tsg_host_border_orders(int32_t n_od, const uint32_t* seed, const int64_t* od_ptr, const int32_t* leg_pair,
                            const int64_t* pair_ptr, const double* pair_p, const int64_t* out_ptr, int32_t* out_idx,
                            int32_t max_size);
+
+/* Hop distances of many OD pairs over the successor CSR (indptr [n+1], indices): out[i] = transitions on a shortest
+ * path origins[i] -> dests[i], -1 when unreachable.  Only the synthetic workloads need it (default_len
+ * = hop distance + 1; the reference's driver takes default_len from the real trajectory's length,
+ * our_model_generate.py:418-424), so it has no counterpart in the reference.  n_threads pthreads (1..64), all joined
+ * before the call returns.  Returns 0, or -1 on an id outside [0, n) or allocation failure. */
+int tsg_host_hop_distance(int32_t n, const int32_t* indptr, const int32_t* indices, int64_t n_od,
+                          const int32_t* origins, const int32_t* dests, int32_t* out, int32_t n_threads);
 
 #ifdef __cplusplus
 }

@@ -9,6 +9,7 @@ that exact-priority ties fall to ``SearchNode.__lt__`` on the node's *current*
 log_prob and then to heap position, as in the reference.
 """
 import heapq
+import time
 import math
 
 import numpy as np
@@ -41,6 +42,13 @@ class SearchStats(object):
         self.model_calls = 0
         self.status = UNTOUCHED
         self.pops = []          # (rid, priority) of every non-stale pop, in order
+        # diagnostics for the parity tests (they observe the search, they never change it):
+        self.near_tol = None    # when set: relaxations of an OPEN road whose old and new log_prob lie within
+        self.near_relax = []    # near_tol * max(1, |log_prob|) are listed here as (pop index, road, new - old):
+        #                         the `<` of search.py:403 is then decided by the last bits (a documented near-tie)
+        self.keep_traces = False
+        self.deadline = None    # bench.py's CPU baseline: stop at this time.time() (the expansions so far are counted)
+        self.traces = []        # with keep_traces: the trajectory (trace_loc) of every non-stale pop
 
 
 def travel_cost(rtd, road_length, hour, rid):
@@ -76,6 +84,8 @@ def astar_search(model, adjacent_list, road_center_gps, road_length, rtd, trace_
     best_trace = None
     best_score = 0
     while open_set and step < max_step:                                  # :279
+        if stats.deadline is not None and time.time() > stats.deadline:
+            break
         cost, now = heapq.heappop(open_set)
         now_rid = now.rid
         if now_rid in close_set:                                         # :284-287
@@ -83,6 +93,8 @@ def astar_search(model, adjacent_list, road_center_gps, road_length, rtd, trace_
         close_set.add(now_rid)
         rid2node.pop(now_rid, None)
         stats.pops.append((now_rid, float(cost)))
+        if stats.keep_traces:
+            stats.traces.append(list(now.trace_loc))
         if now_rid == des:                                               # :291-297
             best_trace = (now.trace_loc, now.trace_tim)
             stats.status = REACHED
@@ -109,6 +121,9 @@ def astar_search(model, adjacent_list, road_center_gps, road_length, rtd, trace_
             new_tim = now.trace_tim + [next_code]
             for c, c_lp in zip(cand, cand_lp):
                 c_score = np.exp(c_lp)
+                if stats.near_tol is not None and c in rid2node and \
+                        abs(c_lp - rid2node[c].log_prob) < stats.near_tol * max(1.0, abs(c_lp)):
+                    stats.near_relax.append((len(stats.pops) - 1, c, c_lp - rid2node[c].log_prob))
                 if c not in rid2node and c not in close_set:             # :388 / :319
                     node = _Node(now.trace_loc + [c], new_tim, c, next_time, c_lp)
                     heapq.heappush(open_set, (-c_lp, node))

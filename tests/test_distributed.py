@@ -35,7 +35,10 @@ def _worker(rank, world, port, n, q):
     ms = rng.randint(1, 50, n)
     res = generate_sharded(fake_local_generate, start, tim, des, dlen, ms, lmax=LMAX)
     ref = fake_local_generate(start, tim, des, dlen, ms)
-    ok = all(torch.equal(res[k].cpu(), ref[k]) for k in ref)
+    w = res['width']
+    ok = w == int(ref['len'].max()) and all(
+        torch.equal(res[k].cpu(), ref[k][:, :w] if ref[k].dim() == 2 else ref[k]) for k in ref)
+    ok = ok and all(int(ref[k][:, w:].abs().sum()) == 0 for k in ('rid', 'time'))      # nothing beyond the trimmed width
     q.put((rank, ok))
     dist.barrier()
     dist.destroy_process_group()

@@ -27,6 +27,7 @@ PREFIX_LENS = (1, 2, 17, 64, 65, 200, 256)
 
 # near-ties recorded on MI355X (deterministic kernels: the counts do not vary from run to run)
 RECORDED_NEAR_TIES = {1: 8, 0: 9}
+RECORDED_RELAX_TIES = {1: 2, 0: 2}
 
 
 @pytest.fixture(scope='module')
@@ -46,7 +47,13 @@ def test_g11_reference_at_bj_dims(world, state_format):
     cap = int(w.z['npop'].max()) + 64
     res = s.generate(model, od['start'], od['start_time'], od['des'], od['default_len'], max_step=w.MAX_STEP,
                      slots=256, lmax=256, poplog_cap=cap)
-    kinds, worst, n_cmp, where, order_only = [], 0.0, 0, None, 0
+    kinds, worst, n_cmp, where, order_only, relax_ties, all_rel = [], 0.0, 0, None, 0, [], []
+    om_box = []
+
+    def oracle():
+        if not om_box:
+            om_box.append(w.oracle_model(model, cfg))
+        return om_box[0]
     for i in range(256):
         c = w.case(i)
         kind = classify_traj(res, i, c['loc'], c['tim'], c['pop_rid'], c['pop_prio'])
@@ -64,21 +71,61 @@ def test_g11_reference_at_bj_dims(world, state_format):
             kind = 'near-tie'
             order_only += 1
         kinds.append(kind)
-        # every priority up to the divergence (all of them for an exact search) within 1e-4 relative of the reference
+        # Every priority up to the divergence (all of them for an exact search) within 1e-4 relative of the reference.
+        # Numerical error is far smaller (~1e-7: see worst_clean below).  A deviation above 1e-5 has another cause:
+        # the relaxation of an open road whose old and new log_prob agree to the last bits (search.py:403's `<`, a
+        # near-tie): the road keeps the other parent, its own priority is the same, but everything expanded
+        # behind it carries a different prefix through the recurrence.  Such a deviation must be PROVEN: the
+        # oracle (pinned to this very golden) re-runs the search and must show a near-tie relaxation, made earlier,
+        # on the path of the deviating pop; the pops of that search behind it are then not compared.
         rel = np.abs(got[:head] - want[:head]) / np.maximum(np.abs(want[:head]), 1.0)   # below 1 (the start node's 0): absolute
+        if head and float(rel.max()) > RTOL:
+            raise AssertionError('OD %d: priority off by %g relative at pop %d' % (i, rel.max(), int(rel.argmax())))
+        big = np.flatnonzero(rel > 1e-5)
+        if len(big):
+            j = int(big[0])
+            st = _oracle_search(w, oracle(), i)
+            assert [p[0] for p in st.pops] == c['pop_rid']
+            path = set(st.traces[j])
+            proof = [r for r in st.near_relax if r[0] < j and r[1] in path]
+            assert proof, 'OD %d: priority off by %g relative at pop %d and no near-tie relaxation on its path' % (
+                i, rel[j], j)
+            relax_ties.append((i, j, float(rel[j]), proof[0]))
+            head, rel = j, rel[:j]
         n_cmp += head
         if head:
+            all_rel.append(rel)
             if float(rel.max()) > worst:
-                j = int(rel.argmax())
-                worst, where = float(rel.max()), (i, j, float(want[j]), float(got[j]))
-            assert rel.max() <= RTOL, 'OD %d: priority off by %g relative at pop %d' % (i, rel.max(), int(rel.argmax()))
+                jj = int(rel.argmax())
+                worst, where = float(rel.max()), (i, jj, float(want[jj]), float(got[jj]))
     print('[g11] state_format %d: worst relative priority error over %d of %d pops: %.3g (OD %d, pop %d: reference '
-          '%.7g, here %.7g); %d of the near-ties below change the pop order only (same trajectory)'
-          % ((state_format, n_cmp, int(w.z['npop'].sum()), worst) + where + (order_only,)))
+          '%.7g, here %.7g); %d of the near-ties below change the pop order only (same trajectory); near-tie '
+          'relaxations that change the path behind a road (OD, pop, relative deviation there, (pop, road, gap) of '
+          'the relaxation): %s' % ((state_format, n_cmp, int(w.z['npop'].sum()), worst) + where + (order_only, relax_ties)))
+    q = np.quantile(np.concatenate(all_rel), [0.5, 0.99, 0.9999])
+    print('[g11] relative priority error: median %.2g, 99 %% %.2g, 99.99 %% %.2g' % tuple(q))
+    assert worst <= 1e-5 and len(relax_ties) <= RECORDED_RELAX_TIES[state_format]
     report_near_ties('G11 reference at BJ dims, state_format %d' % state_format, kinds, RECORDED_NEAR_TIES[state_format])
     lens = res['len'].numpy()
     assert (lens[[k == 'exact' for k in kinds]] == w.z['len'][[k == 'exact' for k in kinds]]).all()
     assert n_cmp >= 0.95 * int(w.z['npop'].sum())      # the near-ties leave nearly every pop compared
+
+
+def _oracle_search(w, om, i):
+    """OD pair i of G11 through the oracle, single-threaded torch (batch-1 model calls), with the diagnostics on."""
+    from oracle import search as osr
+    st = osr.SearchStats()
+    st.near_tol, st.keep_traces = 1e-5, True
+    threads = torch.get_num_threads()
+    torch.set_num_threads(1)
+    try:
+        osr.astar_search(om, w.net.adjacent_list, w.net.rid_gps, w.net.road_length,
+                         w.net.road_time_distribution.astype(int), [int(w.od['start'][i])],
+                         [int(w.od['start_time'][i])], int(w.od['des'][i]), int(w.od['default_len'][i]), w.MAX_STEP,
+                         stats=st)
+    finally:
+        torch.set_num_threads(threads)
+    return st
 
 
 def _prefix_cases(w, n_per_len=6, seed=11):

@@ -56,7 +56,7 @@ def test_host_library_exports_every_declared_symbol():
         pytest.fail('libtsg_host.so is not built: run __graft_entry__.build()')
     header = open(os.path.join(ROOT, 'include', 'tsg_host.h')).read()
     declared = set(re.findall(r'^int (tsg_host_\w+)\(', header, flags=re.M))
-    assert declared == {'tsg_host_border_orders'}
+    assert declared == {'tsg_host_border_orders', 'tsg_host_hop_distance'}
     lib = ctypes.CDLL(lib_path)
     for name in declared:
         assert hasattr(lib, name), name
@@ -161,6 +161,25 @@ def test_border_orders_equal_randomstate_choice():
             want = r.choice(pairs_a[q], len(pairs_a[q]), p=pairs_p[q], replace=False)
             got = pairs_a[q][out_idx[out_ptr[l]:out_ptr[l + 1]]]
             assert np.array_equal(want, got), (i, k)
+
+
+def test_native_hop_distance_equals_scipy():
+    """tsg_host_hop_distance (early-exit BFS per OD pair, pthreads) against scipy's BFS on the 16 x 16 golden street
+    grid (dead ends, unreachable destinations) and on a thinned synthetic graph; origin == destination gives 0."""
+    from ts_trajgen_amd import synth
+    for net in (synth.street_grid_network(12), synth.porto_scale_network()):
+        rs = np.random.RandomState(4)
+        n = net.num_roads
+        o = rs.randint(0, n, size=600)
+        d = rs.randint(0, n, size=600)
+        d[:5] = o[:5]
+        want = synth.hop_distance(net, o, d, native=False)
+        for workers in (1, 3):
+            got = synth.hop_distance(net, o, d, workers=workers)
+            assert np.array_equal(want, got)
+        assert (want[:5] == 0).all()
+    with pytest.raises(ValueError):
+        synth.hop_distance(net, [0], [n])
 
 
 def test_border_orders_rejects_what_numpy_rejects():

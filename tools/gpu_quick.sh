@@ -6,7 +6,7 @@ tag=$1; shift
 mkdir -p gpurun_out
 timeout -k 10 600 python -u -m pytest tests -m gpu -x -q --timeout 120 --timeout-method thread > gpurun_out/${tag}_pytest.log 2>&1 || { tail -30 gpurun_out/${tag}_pytest.log; exit 1; }
 tail -1 gpurun_out/${tag}_pytest.log
-timeout -k 10 400 python -u bench.py --cpu-seconds 0 --two-stage-ods 0 --two-engines 0 --steps 1 "$@" > gpurun_out/${tag}_bench.log 2>&1 || { tail -30 gpurun_out/${tag}_bench.log; exit 1; }
+timeout -k 10 400 python -u bench.py --cpu-seconds 0 --two-stage-ods 0 --two-engines 0 --fp32-step 0 --steps 1 "$@" > gpurun_out/${tag}_bench.log 2>&1 || { tail -30 gpurun_out/${tag}_bench.log; exit 1; }
 python - <<PY
 import json
 l=[x for x in open('gpurun_out/${tag}_bench.log') if x.startswith('{')][-1]

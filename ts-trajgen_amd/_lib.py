@@ -168,6 +168,8 @@ def host_lib():
         H = C.CDLL(path)
         H.tsg_host_border_orders.argtypes = [_i32, _p, _p, _p, _p, _p, _p, _p, _i32]
         H.tsg_host_border_orders.restype = C.c_int
+        H.tsg_host_hop_distance.argtypes = [_i32, _p, _p, C.c_int64, _p, _p, _p, _i32]
+        H.tsg_host_hop_distance.restype = C.c_int
         _host = H
     return _host
 

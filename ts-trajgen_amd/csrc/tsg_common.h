@@ -61,8 +61,16 @@ __device__ __forceinline__ float tsg_wave_max_u(float v) {
 }
 
 // v_exp_f32 / v_rcp_f32 forms (about 1e-7 absolute error, far inside the 1e-4 parity budget)
+#ifndef TSG_PRECISE_GATES
+#define TSG_PRECISE_GATES 0  // 1: libm expf / tanhf and a true division (ablation: do fewer near-ties flip?)
+#endif
+#if TSG_PRECISE_GATES
+__device__ __forceinline__ float tsg_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float tsg_tanh(float x) { return tanhf(x); }
+#else
 __device__ __forceinline__ float tsg_sigmoid(float x) { return __frcp_rn(1.0f + __expf(-x)); }
 __device__ __forceinline__ float tsg_tanh(float x) { return 1.0f - 2.0f * __frcp_rn(1.0f + __expf(2.0f * x)); }
+#endif
 
 // slot-state word indices (engine.slot_state is [B][SS_WORDS = 40] int32).  The words are grouped by how often they
 // change, and the frontier kernel writes a group back as whole 16-byte pieces (every store instruction of a lane is

@@ -138,3 +138,98 @@ int tsg_host_border_orders(int32_t n_od, const uint32_t* seed, const int64_t* od
   free(seen);
   return 0;
 }
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Hop distances of many OD pairs (synthetic workloads: default_len = BFS hop distance + 1; the
+ * reference takes default_len from the length of the real trajectory, our_model_generate.py:418-424).  One
+ * breadth-first search per OD pair over the successor CSR, stopped when the destination is reached; OD pair i goes
+ * to thread i % n_threads (plain pthreads, all joined before the call returns: no thread pool is left behind for
+ * a later fork()).  out[i] = number of transitions from origins[i] to dests[i], -1 when unreachable.
+ * Returns 0, -1 on bad arguments (an id outside [0, n)) or allocation failure. */
+#include <pthread.h>
+#include <string.h>
+
+typedef struct {
+  int32_t n;
+  const int32_t* indptr;
+  const int32_t* indices;
+  int64_t n_od;
+  const int32_t* origins;
+  const int32_t* dests;
+  int32_t* out;
+  int tid, n_threads, rc;
+} hop_job;
+
+static void* hop_worker(void* arg) {
+  hop_job* j = (hop_job*)arg;
+  const int32_t n = j->n;
+  int32_t* stamp = (int32_t*)calloc((size_t)n, sizeof(int32_t)); /* epoch of the search that last reached a road */
+  int32_t* queue = (int32_t*)malloc(sizeof(int32_t) * (size_t)n);
+  if (!stamp || !queue) {
+    free(stamp);
+    free(queue);
+    j->rc = -1;
+    return NULL;
+  }
+  int32_t epoch = 0;
+  for (int64_t i = j->tid; i < j->n_od; i += j->n_threads) {
+    const int32_t o = j->origins[i], d = j->dests[i];
+    if (++epoch == INT32_MAX) {
+      memset(stamp, 0, sizeof(int32_t) * (size_t)n);
+      epoch = 1;
+    }
+    int32_t found = o == d ? 0 : -1;
+    int32_t head = 0, tail = 0, level_end = 1, depth = 0;
+    queue[tail++] = o;
+    stamp[o] = epoch;
+    while (found < 0 && head < tail) {
+      if (head == level_end) {
+        ++depth;
+        level_end = tail;
+      }
+      const int32_t r = queue[head++];
+      for (int32_t k = j->indptr[r]; k < j->indptr[r + 1]; ++k) {
+        const int32_t c = j->indices[k];
+        if (stamp[c] == epoch) continue;
+        if (c == d) {
+          found = depth + 1;
+          break;
+        }
+        stamp[c] = epoch;
+        queue[tail++] = c;
+      }
+    }
+    j->out[i] = found;
+  }
+  free(stamp);
+  free(queue);
+  return NULL;
+}
+
+int tsg_host_hop_distance(int32_t n, const int32_t* indptr, const int32_t* indices, int64_t n_od,
+                          const int32_t* origins, const int32_t* dests, int32_t* out, int32_t n_threads) {
+  if (n <= 0 || n_od < 0 || !indptr || !indices || !origins || !dests || !out) return -1;
+  for (int64_t i = 0; i < n_od; ++i)
+    if (origins[i] < 0 || origins[i] >= n || dests[i] < 0 || dests[i] >= n) return -1;
+  if (n_threads < 1) n_threads = 1;
+  if (n_threads > 64) n_threads = 64;
+  if ((int64_t)n_threads > n_od) n_threads = n_od > 0 ? (int32_t)n_od : 1;
+  hop_job jobs[64];
+  pthread_t th[64];
+  int started = 0, rc = 0;
+  for (int t = 0; t < n_threads; ++t) {
+    jobs[t] = (hop_job){n, indptr, indices, n_od, origins, dests, out, t, n_threads, 0};
+    if (pthread_create(&th[t], NULL, hop_worker, &jobs[t]) != 0) break;
+    ++started;
+  }
+  for (int t = 0; t < started; ++t) pthread_join(th[t], NULL);
+  for (int t = 0; t < started; ++t)
+    if (jobs[t].rc) rc = -1;
+  if (started < n_threads && rc == 0) { /* threads that could not be started: their share runs here */
+    for (int t = started; t < n_threads; ++t) {
+      hop_worker(&jobs[t]);
+      if (jobs[t].rc) rc = -1;
+    }
+  }
+  return rc;
+}

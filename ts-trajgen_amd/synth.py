@@ -200,11 +200,27 @@ def _bfs_chunk(args):
     return dist[rows, dcol]
 
 
-def hop_distance(net, origins, dests, unreachable=-1, chunk=256, workers=1):
+def hop_distance(net, origins, dests, unreachable=-1, chunk=256, workers=1, native=True):
     """BFS hop count from each origin to its destination (number of transitions).
-    `workers` > 1 forks a process pool: call it before the process has touched the GPU."""
+    native: libtsg_host.so's tsg_host_hop_distance (one early-exit BFS per OD pair, `workers` pthreads joined
+    before it returns; 131 072 OD pairs at BJ scale in seconds where the scipy form below takes minutes);
+    otherwise scipy's all-destinations BFS per distinct origin, `workers` > 1 forking a process pool (call it
+    before the process has touched the GPU).  Both give the same numbers (tests/test_host.py)."""
     n = net.num_roads
     indptr, indices = csr_from_adjacent_list(net.adjacent_list, n)
+    if native:
+        import ctypes as C
+        from . import _lib
+        o32 = np.ascontiguousarray(origins, dtype=np.int32)
+        d32 = np.ascontiguousarray(dests, dtype=np.int32)
+        ip = np.ascontiguousarray(indptr, dtype=np.int32)
+        ix = np.ascontiguousarray(indices if len(indices) else np.zeros(1), dtype=np.int32)
+        res = np.zeros(len(o32), dtype=np.int32)
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        rc = _lib.host_lib().tsg_host_hop_distance(n, p(ip), p(ix), len(o32), p(o32), p(d32), p(res), max(1, int(workers)))
+        if rc != 0:
+            raise ValueError('tsg_host_hop_distance failed (%d): a road id outside [0, %d)?' % (rc, n))
+        return np.where(res >= 0, res, unreachable).astype(np.int64)
     origins = np.asarray(origins, dtype=np.int64)
     dests = np.asarray(dests, dtype=np.int64)
     out = np.full(len(origins), unreachable, dtype=np.int64)
