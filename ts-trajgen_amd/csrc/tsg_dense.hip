@@ -553,8 +553,23 @@ __device__ __forceinline__ void lstm_layer_split_body(const LstmArgs& a) {
                         (_Float16)2048.0f, (_Float16)2048.0f, (_Float16)2048.0f, (_Float16)2048.0f};
   // one k-tile: the rows of tile KT+1 (requested one step ago) go to the wave's LDS stretch, whose previous
   // content (tile KT) is already in ca*; then the rows of tile KT+2 and the weights of tile KT+1 are requested
+#ifndef TSG_IGLP
+#define TSG_IGLP -1  // scheduling experiments: 0 / 1 = __builtin_amdgcn_iglp_opt(n) in the k-step, 2 = sched_group_barrier pattern
+#endif
+#if TSG_IGLP == 0 || TSG_IGLP == 1
+#define TSG_KSTEP_SCHED __builtin_amdgcn_iglp_opt(TSG_IGLP);
+#elif TSG_IGLP == 2
+#define TSG_KSTEP_SCHED                                                                                     \
+  _Pragma("unroll") for (int q_ = 0; q_ < 8; ++q_) {                                                        \
+    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); /* 2 DS reads */                                    \
+    __builtin_amdgcn_sched_group_barrier(0x008, 3, 0); /* 3 MFMA */                                        \
+  }
+#else
+#define TSG_KSTEP_SCHED
+#endif
 #define TSG_KSTEP(KT, CUR, MORE)                                                                            \
   {                                                                                                         \
+    TSG_KSTEP_SCHED                                                                                         \
     if (MORE) {                                                                                             \
       gload_w((KT) + 1);                                                                                    \
       TSG_ASTORE((KT) + 1)                                                                                  \

@@ -152,6 +152,34 @@ __device__ __forceinline__ void attn_fold4(AttnAcc<JT>& s, float key[4][JT], uns
   s.m = mn;
 }
 
+// N rows that all exist (the caller names a valid row for every u and masks the absent ones when it folds): no
+// branch between the loads.  With a branch per row (attn_load_n's null check, load_row's run-time J test) the compiler
+// puts `s_waitcnt vmcnt(0)` in front of every row load (the registers it writes may, on some path through the
+// branches, still be the target of a load in flight), and a group's rows then travel one after the other.
+// VEC4: hp == 256, one dwordx4 per lane and row; otherwise lane owns elements lane + 64 j, j < J.
+template <int JT, int N, bool VEC4>
+__device__ __forceinline__ void attn_load_rows(float key[N][JT], const float* const rows[N], int J, int lane) {
+  if (VEC4) {
+    static_assert(!VEC4 || JT == 4, "one dwordx4 per lane: hp == 256");
+#pragma unroll
+    for (int u = 0; u < N; ++u) {
+      const float4 v = *reinterpret_cast<const float4*>(rows[u] + 4 * lane);
+      key[u][0] = v.x;
+      key[u][1] = v.y;
+      key[u][2] = v.z;
+      key[u][3] = v.w;
+    }
+  } else {
+#pragma unroll
+    for (int u = 0; u < N; ++u)
+#pragma unroll
+      for (int j = 0; j < JT; ++j) {
+        const float v = rows[u][lane + 64 * (j < J ? j : 0)];
+        key[u][j] = j < J ? v : 0.0f;  // a select, not a branch
+      }
+  }
+}
+
 // The same in groups of N rows (the engine's scoring kernel keeps two groups of eight in flight).
 template <int JT, int N>
 __device__ __forceinline__ void attn_load_n(float key[N][JT], const float* const rows[N], int J, int lane) {
@@ -210,6 +238,17 @@ __device__ __forceinline__ float tsg_h_logit(const tsg_model& m, int cand, int d
   const float* hpar = m.hparams;
   const float* pf = m.pfrom + (size_t)cand * TSG_H_HIDDEN;
   const float* pt = m.pto + (size_t)des * TSG_H_HIDDEN;
+  float acc = hpar[40];
+#pragma unroll
+  for (int j = 0; j < TSG_H_HIDDEN; ++j) acc += hpar[20 + j] * fmaxf(pf[j] + pt[j], 0.0f);
+#pragma unroll
+  for (int j = 0; j < TSG_H_HIDDEN; ++j) acc += hpar[30 + j] * fmaxf(hpar[j] * dis + hpar[10 + j], 0.0f);
+  return acc;
+}
+
+// The same from rows already in registers (pf = pfrom[cand], pt = pto[des]): identical arithmetic, term by term.
+__device__ __forceinline__ float tsg_h_logit_regs(const float hpar[42], const float pf[TSG_H_HIDDEN],
+                                                  const float pt[TSG_H_HIDDEN], float dis) {
   float acc = hpar[40];
 #pragma unroll
   for (int j = 0; j < TSG_H_HIDDEN; ++j) acc += hpar[20 + j] * fmaxf(pf[j] + pt[j], 0.0f);

@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void cand_dis_kernel(EngineDev D, int superste
 // (anc[e][0] = parent, anc[e][i] = anc[parent][i-1]) and then already holds, one per lane, the slots whose
 // top-layer hidden rows the attention needs: no pointer chase, the key rows are independent coalesced
 // loads.  Chains longer than 64 hop through anc[.][63] once per 64 rows.
-template <int JT, bool SPLIT>
+template <int JT, bool SPLIT, bool VEC4>
 __global__ __launch_bounds__(256) void score_frontier_kernel(tsg_model m, EngineDev D, int superstep) {
   // wave w of the launch -> position w / R of region w % R of the work list: the fronts of all regions (long
   // ancestor chains) start first, the empty middle exits at once, the short chains fill in behind
@@ -164,61 +164,155 @@ __global__ __launch_bounds__(256) void score_frontier_kernel(tsg_model m, Engine
   const int region = w % nreg, pos = w / nreg;
   const int rs = tsg_region_size(D.e.slots, region);
   if (pos >= rs) return;
+  // Round trip 1: the counters of the region and the item words together (the words of a position that is not
+  // filled in this superstep are stale but in range).  The empty asm statements make the compiler issue the loads
+  // HERE: left alone it sinks every load below the early returns, one dependent round trip after the other
+  // (counters, item, ancestor list, candidates, function H's rows: five before the first key row was requested).
   const int32_t* it = D.e.items + ((size_t)region * TSG_REGION_SLOTS + pos) * IT_WORDS;
+  int4 w0 = reinterpret_cast<const int4*>(it)[0];  // IT_SLOT, IT_ROW, IT_PROW, IT_RID
+  int4 w1 = reinterpret_cast<const int4*>(it)[1];  // IT_TCODE, IT_NCAND, IT_DES, IT_LP
+  int depth = it[IT_DEPTH];                        // = number of rows on the ancestor chain incl. e
   int n_long, n_short;
   tsg_item_counts(D.e.item_counts, D.e.counters, D.e.slots, region, n_long, n_short);
-  const int ncand = it[IT_NCAND];
-  const int b = it[IT_SLOT], e = it[IT_ROW];  // e: the state row of the expanded node
+  float hpar[42];  // function H's small layers and w1: the same for every wave, read through the scalar cache (before
+                   // this wave's first store: behind it the compiler would fall back to 42 vector loads per lane)
+#pragma unroll
+  for (int k = 0; k < 42; ++k) hpar[k] = m.hparams[k];
+  asm volatile("" : "+v"(w0.x), "+v"(w1.x), "+v"(depth), "+v"(n_long), "+v"(n_short));
+  if (!tsg_item_filled(pos, rs, n_long, n_short)) return;  // not filled in this superstep
+  // the item is the same for all lanes: its words go to scalar registers (and what they address with the same
+  // offset in all lanes, function H's destination row, comes through the scalar cache)
+  const int b = __builtin_amdgcn_readfirstlane(w0.x), e = __builtin_amdgcn_readfirstlane(w0.y);  // e: the state row of the expanded node
+  const int parent = __builtin_amdgcn_readfirstlane(w0.z);
+  const int ncand = __builtin_amdgcn_readfirstlane(w1.y), des = __builtin_amdgcn_readfirstlane(w1.z);
+  const float lp_parent = __int_as_float(__builtin_amdgcn_readfirstlane(w1.w));
+  depth = __builtin_amdgcn_readfirstlane(depth);
   constexpr int LV = TSG_UP_LEVELS;  // = 64 ancestors per row
   int32_t* anc = D.e.exp_up;
-  const int parent = it[IT_PROW];
-  if (!tsg_item_filled(pos, rs, n_long, n_short)) return;  // not filled in this superstep (the words above are stale)
-  // lane i: the state row of the (i+1)-th ancestor; kept in a register (this wave must not read back its own store)
-  int mine = lane == 0 ? parent : (parent >= 0 ? anc[(size_t)parent * LV + lane - 1] : -1);
-  anc[(size_t)e * LV + lane] = mine;
-  const int des = it[IT_DES];
-  if (ncand < 2) return;  // warm-up rows and single-successor expansions need no model call (search.py:302)
-  const float lp_parent = __int_as_float(it[IT_LP]);
+  const int md = D.g.max_degree;
   const int hp = m.hp, J = hp / 64;
   const float* htop = D.e.h[m.n_layers - 1];
-  const int depth = it[IT_DEPTH];  // = number of rows on the ancestor chain incl. e
+  const bool scored = ncand >= 2;  // warm-up rows and single-successor expansions need no model call (search.py:302)
+  const bool on = lane < ncand && scored;
+  // Round trip 2, everything the item words address: the parent's ancestor list, and for a scored item the query
+  // row, the successor ids and distances (left by the frontier and distance kernels) and function H's
+  // destination terms.
+  // lane i: the state row of the (i+1)-th ancestor; kept in a register (this wave must not read back its own store)
+  int mine = lane == 0 ? parent : (parent >= 0 ? anc[(size_t)parent * LV + lane - 1] : -1);
   float q[JT];
-  load_row<JT, SPLIT>(htop + (size_t)e * hp, q, J, lane);
+#pragma unroll
+  for (int j = 0; j < JT; ++j) q[j] = 0.0f;
+  int my_cand = 0;
+  float my_dis = 0.0f;
+  float pt[TSG_H_HIDDEN];
+#pragma unroll
+  for (int j = 0; j < TSG_H_HIDDEN; ++j) pt[j] = 0.0f;
+  if (scored) {
+    {  // raw words: decoded below, after the next loads are out
+      const float* qrow[1] = {htop + (size_t)e * hp};
+      float q1[1][JT];
+      attn_load_rows<JT, 1, VEC4>(q1, qrow, J, lane);
+#pragma unroll
+      for (int j = 0; j < JT; ++j) q[j] = q1[0][j];
+    }
+    if (on) {
+      my_cand = D.e.cand_id[(size_t)b * md + lane];
+      my_dis = D.e.cand_lp[(size_t)b * md + lane];  // written by the distance workgroups of this superstep
+    }
+    const float* ptp = m.pto + (size_t)des * TSG_H_HIDDEN;
+#pragma unroll
+    for (int j = 0; j < TSG_H_HIDDEN; ++j) pt[j] = ptp[j];
+  }
+  asm volatile("" : "+v"(mine), "+v"(my_cand));
+  anc[(size_t)e * LV + lane] = mine;
+  if (!scored) return;
+  // Round trip 3: function H's candidate rows and the out_fc bias (they need the successor id) go out in front of
+  // the first group of key rows; H's score is finished before the attention loop is entered and costs one
+  // register from there on.
+  float pf[TSG_H_HIDDEN];
+  float out_bias = 0.0f;
+  {
+    const float* pfp = m.pfrom + (size_t)my_cand * TSG_H_HIDDEN;
+#pragma unroll
+    for (int j = 0; j < TSG_H_HIDDEN; ++j) pf[j] = pfp[j];
+    out_bias = m.out_b[my_cand];
+  }
+  if (SPLIT) {
+#pragma unroll
+    for (int j = 0; j < JT; ++j) q[j] = tsg_state_value(q[j]);
+  }
   AttnAcc<JT> acc;
   attn_init(acc);
   int anchor = e;   // the (64 * chunk)-th ancestor
   int list = mine;  // lane i: the (i+1)-th ancestor of `anchor`
-  for (int base = 0; base < depth; base += 64) {
-    const int n = depth - base < 64 ? depth - base : 64;
-    // lane t: the ancestor at distance t of `anchor` (lane 0 = the anchor itself)
-    const int up1 = __shfl_up(list, 1, TSG_WAVE);
-    const int cur = lane == 0 ? anchor : up1;
-    // groups of TSG_SCORE_GROUP rows, software-pipelined: group g+1 is loading while group g is folded
-    constexpr int G = TSG_SCORE_GROUP;
-    float keyA[G][JT], keyB[G][JT];
-    unsigned presA = 0, presB = 0;
-    auto issue = [&](int i, float key[G][JT], unsigned& pres) {
-      const float* rows[G];
-      pres = 0;
+  constexpr int G = TSG_SCORE_GROUP;
+  float keyA[G][JT], keyB[G][JT];
+  bool w_in_a = false;
+  // the out_fc rows of candidates 0 .. G-1 (function_g_fc.py:184-186: only the rows that are needed), as one more group
+  auto issue_w = [&](float key[G][JT]) {
+    const float* rows[G];
 #pragma unroll
-      for (int u = 0; u < G; ++u) {
-        const int src_lane = i + u < n ? i + u : n - 1;
-        const int id = __shfl(cur, src_lane, TSG_WAVE);
-        rows[u] = (i + u < n) ? htop + (size_t)id * hp : nullptr;
-        if (rows[u]) pres |= 1u << u;
-      }
-      attn_load_n<JT, G>(key, rows, J, lane);
-    };
-    issue(0, keyA, presA);
+    for (int u = 0; u < G; ++u) {
+      const int cid = __shfl(my_cand, u < ncand ? u : ncand - 1, TSG_WAVE);
+      rows[u] = m.out_w + (size_t)cid * hp;
+    }
+    attn_load_rows<JT, G, VEC4>(key, rows, J, lane);
+  };
+  // groups of TSG_SCORE_GROUP rows, software-pipelined: group g+1 is loading while group g is folded
+  int n = depth < 64 ? depth : 64;  // rows of the current chunk of 64 ancestors
+  int cur = 0;                      // lane t: the ancestor at distance t of `anchor` (lane 0 = the anchor itself)
+  unsigned presA = 0, presB = 0;
+  auto issue = [&](int i, float key[G][JT], unsigned& pres) {
+    const float* rows[G];
+    pres = 0;
+#pragma unroll
+    for (int u = 0; u < G; ++u) {
+      // a position beyond the chain reads the chain's last row again (a row that exists) and is masked in the fold
+      const int src_lane = i + u < n ? i + u : n - 1;
+      const int id = __shfl(cur, src_lane, TSG_WAVE);
+      rows[u] = htop + (size_t)id * hp;
+      if (i + u < n) pres |= 1u << u;
+    }
+    attn_load_rows<JT, G, VEC4>(key, rows, J, lane);
+  };
+  {
+    const int up1 = __shfl_up(list, 1, TSG_WAVE);
+    cur = lane == 0 ? anchor : up1;
+  }
+  issue(0, keyA, presA);
+  float h_logit = -INFINITY;
+  bool h_pending = true;
+  for (int base = 0; base < depth; base += 64) {
+    const bool last_chunk = base + 64 >= depth;
+    if (base > 0) {
+      n = depth - base < 64 ? depth - base : 64;
+      const int up1 = __shfl_up(list, 1, TSG_WAVE);
+      cur = lane == 0 ? anchor : up1;
+      issue(0, keyA, presA);
+    }
     for (int i = 0; i < n; i += 2 * G) {
-      if (i + G < n) issue(i + G, keyB, presB);
+      if (i + G < n) {
+        issue(i + G, keyB, presB);
+      } else if (last_chunk) {
+        issue_w(keyB);
+        w_in_a = false;
+      }
+      if (h_pending) {  // function H's score, once, while the first two groups of rows travel
+        h_logit = on ? tsg_h_logit_regs(hpar, pf, pt, my_dis) : -INFINITY;
+        h_pending = false;
+      }
       attn_fold_n<JT, G, SPLIT>(acc, keyA, presA, q);
       if (i + G < n) {
-        if (i + 2 * G < n) issue(i + 2 * G, keyA, presA);
+        if (i + 2 * G < n) {
+          issue(i + 2 * G, keyA, presA);
+        } else if (last_chunk) {
+          issue_w(keyA);
+          w_in_a = true;
+        }
         attn_fold_n<JT, G, SPLIT>(acc, keyB, presB, q);
       }
     }
-    if (base + 64 < depth) {  // next chunk: hop 64 up, fetch that slot's list
+    if (!last_chunk) {  // next chunk: hop 64 up, fetch that slot's list
       anchor = __shfl(list, 63, TSG_WAVE);
       list = anc[(size_t)anchor * LV + lane];
     }
@@ -227,14 +321,43 @@ __global__ __launch_bounds__(256) void score_frontier_kernel(tsg_model m, Engine
   const float inv = 1.0f / acc.l;
 #pragma unroll
   for (int j = 0; j < JT; ++j) pooled[j] = acc.v[j] * inv;
-  int my_cand = 0;
-  float my_dis = 0.0f;
-  if (lane < ncand) {
-    my_cand = D.e.cand_id[(size_t)b * D.g.max_degree + lane];  // the successor list the frontier kernel left
-    my_dis = D.e.cand_lp[(size_t)b * D.g.max_degree + lane];   // written by cand_dis_kernel
+  // G: the candidates' out_fc rows . pooled (+ bias); the first group is already in registers
+  float g_logit = -INFINITY;
+  {
+    float part[G];
+#pragma unroll
+    for (int u = 0; u < G; ++u) {
+      float p = 0.0f;
+#pragma unroll
+      for (int j = 0; j < JT; ++j) p += (w_in_a ? keyA[u][j] : keyB[u][j]) * pooled[j];
+      part[u] = p;
+    }
+#pragma unroll
+    for (int u = 0; u < G; ++u) part[u] = tsg_wave_sum_u(part[u]);
+#pragma unroll
+    for (int u = 0; u < G; ++u)
+      if (lane == u && u < ncand) g_logit = part[u] + out_bias;
   }
-  const float f = score_row<JT>(m, pooled, J, lane, ncand, my_cand, my_dis, des, nullptr, nullptr);
-  if (lane < ncand) D.e.cand_lp[(size_t)b * D.g.max_degree + lane] = logf(f) + lp_parent;  // search.py:370-373
+  for (int c0 = G; c0 < ncand; c0 += 4) {  // more than G successors (rare on road graphs)
+    float part[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int c = c0 + u < ncand ? c0 + u : ncand - 1;
+      const int cid = __shfl(my_cand, c, TSG_WAVE);
+      float w[JT];
+      load_row<JT>(m.out_w + (size_t)cid * hp, w, J, lane);
+      part[u] = 0.0f;
+#pragma unroll
+      for (int j = 0; j < JT; ++j) part[u] += w[j] * pooled[j];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) part[u] = tsg_wave_sum_u(part[u]);
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (lane == c0 + u && c0 + u < ncand) g_logit = part[u] + out_bias;
+  }
+  const float f = tsg_mix_softmax(m, g_logit, h_logit, on, nullptr, nullptr);
+  if (on) D.e.cand_lp[(size_t)b * md + lane] = logf(f) + lp_parent;  // search.py:370-373
 }
 
 // With the split-f16 recurrence the candidate distances (and the control step) ride on the layer-0 launch as extra
@@ -248,11 +371,15 @@ static void launch_cand_dis(const EngineDev& D, int superstep, hipStream_t s) {
 template <bool SPLIT>
 static void launch_score_frontier_t(const tsg_model* m, const EngineDev& D, int superstep, hipStream_t s) {
   const dim3 grid(tsg_cdiv(tsg_n_regions(D.e.slots) * TSG_REGION_SLOTS, TSG_SCORE_WPB)), blk(64 * TSG_SCORE_WPB);
+  if (m->hp == 256) {  // BJ dims: one 16-byte load per lane and row
+    hipLaunchKernelGGL((score_frontier_kernel<4, SPLIT, true>), grid, blk, 0, s, *m, D, superstep);
+    return;
+  }
   switch (jt_for(m->hp)) {
-    case 1: hipLaunchKernelGGL((score_frontier_kernel<1, SPLIT>), grid, blk, 0, s, *m, D, superstep); break;
-    case 2: hipLaunchKernelGGL((score_frontier_kernel<2, SPLIT>), grid, blk, 0, s, *m, D, superstep); break;
-    case 4: hipLaunchKernelGGL((score_frontier_kernel<4, SPLIT>), grid, blk, 0, s, *m, D, superstep); break;
-    default: hipLaunchKernelGGL((score_frontier_kernel<8, SPLIT>), grid, blk, 0, s, *m, D, superstep); break;
+    case 1: hipLaunchKernelGGL((score_frontier_kernel<1, SPLIT, false>), grid, blk, 0, s, *m, D, superstep); break;
+    case 2: hipLaunchKernelGGL((score_frontier_kernel<2, SPLIT, false>), grid, blk, 0, s, *m, D, superstep); break;
+    case 4: hipLaunchKernelGGL((score_frontier_kernel<4, SPLIT, false>), grid, blk, 0, s, *m, D, superstep); break;
+    default: hipLaunchKernelGGL((score_frontier_kernel<8, SPLIT, false>), grid, blk, 0, s, *m, D, superstep); break;
   }
 }
 

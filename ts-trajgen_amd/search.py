@@ -107,6 +107,14 @@ class Searcher(object):
     # 1: hidden states as split-f16 words, recurrence on the f16 matrix cores in three passes (fp32-grade
     # products, include/tsg.h tsg_engine.state_format); 0: plain fp32 states on the fp32 matrix-core path
     state_format = 1
+    # Memory policy of generate() when the caller gives no sizes: the share of the device memory that is free
+    # (driver-free + torch's cached-but-unused blocks + what this Searcher's own engines hold) an engine may take.
+    # Large plain batches (>= AUTO_PLAN_MIN_OD pairs) are planned against `plan_budget_frac`, everything else
+    # against `budget_frac`.  A caller that allocates afterwards (a training loop, a second model) lowers them on
+    # its Searcher, or passes slots / pool_pages itself, or sets auto_plan = False.
+    budget_frac = 0.6
+    plan_budget_frac = 0.93
+    auto_plan = True
 
     def __init__(self, device, adjacent_list, road_center_gps=None, road_length=None, road_time_distribution=None):
         self.device = torch.device(device)
@@ -118,14 +126,6 @@ class Searcher(object):
         self._engines = {}
         self._streams = []          # one per engine of a side-by-side run, kept for the Searcher's life
         self._stream_report = {}    # streams_apart's verdict on them ('queues_apart'), copied into last_stats
-        # Memory policy of generate() when the caller gives no sizes: the share of the device memory that is free
-        # (driver-free + torch's cached-but-unused blocks + what this Searcher's own engines hold) an engine may
-        # take.  Large plain batches (>= AUTO_PLAN_MIN_OD pairs) are planned against `plan_budget_frac`, everything
-        # else against `budget_frac`.  A caller that allocates afterwards (a training loop, a second model) lowers
-        # them, or passes slots / pool_pages itself, or sets auto_plan = False.
-        self.budget_frac = 0.6
-        self.plan_budget_frac = 0.93
-        self.auto_plan = True
         self._label_key = None
 
     # -- device substrate ------------------------------------------------------------------------
@@ -502,6 +502,7 @@ class DoubleLayerSearcher(object):
                                                self.region_time_distribution, len(self.region2rid))
             s._engines = {}
             s._streams = []
+            s._stream_report = {}
             s._label_key = None
             self._region_search = s
         return self._region_search
