@@ -399,6 +399,9 @@ __device__ __forceinline__ unsigned tsg_split_word(float x) {
   return (unsigned)__builtin_bit_cast(unsigned short, mj) | ((unsigned)__builtin_bit_cast(unsigned short, mn) << 16);
 }
 
+#ifndef TSG_TQ
+#define TSG_TQ 4  // rows of tproj requested ahead in layer 0's epilogue
+#endif
 #ifndef TSG_LSTM_STAMP
 #define TSG_LSTM_STAMP 0  // diagnostic build only: where a wave of the recurrence spends its time (never shipped)
 #endif
@@ -613,14 +616,14 @@ __device__ __forceinline__ void lstm_layer_split_body(const LstmArgs& a) {
 #undef TSG_ASTORE
 #undef TSG_ALOAD
   LSTAMP(2)
-  float4 tq[4];
+  float4 tq[TSG_TQ];
   auto tload = [&](int i) {
     const int r = wave * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
     return *reinterpret_cast<const float4*>(a.tproj + (size_t)s_tc[r] * ldw + 4 * u);
   };
   if (LAYER0) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) tq[i] = tload(i);
+    for (int i = 0; i < TSG_TQ; ++i) tq[i] = tload(i);
   }
   unsigned* hs_out = reinterpret_cast<unsigned*>(a.h);
   const float inv = 1.0f / 2048.0f;
@@ -629,8 +632,8 @@ __device__ __forceinline__ void lstm_layer_split_body(const LstmArgs& a) {
     const int r = wave * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
     float4 tv = make_float4(0.f, 0.f, 0.f, 0.f);
     if (LAYER0) {
-      tv = tq[i & 3];
-      if (i + 4 < 16) tq[i & 3] = tload(i + 4);
+      tv = tq[i % TSG_TQ];
+      if (i + TSG_TQ < 16) tq[i % TSG_TQ] = tload(i + TSG_TQ);
     }
     const float zi = acc[0][i] * inv + tv.x, zf = acc[1][i] * inv + tv.y;
     const float zg = acc[2][i] * inv + tv.z, zo = acc[3][i] * inv + tv.w;

@@ -127,14 +127,29 @@ TSG_HD void heap_push(uint64_t* h, int& n, HeapEnt item, const int32_t* nodes, i
 // blocks rooted at the children of the current entry) gives three levels per round trip; the decisions are the
 // same comparisons in the same order.  _siftdown's first comparison is against the entry the sift moved last,
 // which is still in a register.
-TSG_HD HeapEnt heap_pop(uint64_t* h, int& n, const int32_t* nodes) {
+// `side`: the caller's own chain of look-ups for the entry that is being popped (its node record, then what the
+// record addresses, then what that addresses) rides along with the sift: side.begin(node) is called as soon as the
+// popped entry is known (one round trip into the pop), side.step() once per round trip of the sift, right after
+// that round trip's loads have been requested; the sift only reads node records and writes the queue, so the two
+// chains are independent and share their round trips instead of following each other.  The caller finishes what is
+// left of its chain after the pop (side.finish()).  NoSide: nothing rides along (host harness, tests).
+struct HeapNoSide {
+  TSG_HD void begin(int) {}
+  TSG_HD void step() {}
+};
+template <class Side>
+TSG_HD HeapEnt heap_pop(uint64_t* h, int& n, const int32_t* nodes, Side& side) {
   const HeapEnt last = ent_of(h[heap_addr(n)]);
   --n;
-  if (n == 0) return last;
+  if (n == 0) {
+    side.begin(last.node);
+    return last;
+  }
   const uint4* rb = reinterpret_cast<const uint4*>(h + 8);  // the root's block: words 8..15
   const uint4 r0 = rb[0], r1 = rb[1], r2 = rb[2], r3 = rb[3];
   auto w64 = [](unsigned lo, unsigned hi) { return (uint64_t)lo | ((uint64_t)hi << 32); };
   const HeapEnt ret = ent_of(w64(r0.z, r0.w));
+  side.begin(ret.node);
   int j = 1;
   uint64_t moved = 0;  // the entry that went from `j` to its parent in the latest step
   if (2 <= n) {
@@ -161,6 +176,7 @@ TSG_HD HeapEnt heap_pop(uint64_t* h, int& n, const int32_t* nodes) {
     uint4 q[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) q[i] = pb[i];
+    side.step();
     // level 1: the two local roots
     const uint64_t l1 = w64(q[0].z, q[0].w), x1 = w64(q[4].z, q[4].w);
     int s1 = 0;
@@ -192,6 +208,7 @@ TSG_HD HeapEnt heap_pop(uint64_t* h, int& n, const int32_t* nodes) {
   while (2 * j <= n) {  // below the blocks: one level per round trip, the two children side by side
     const int c = 2 * j;
     const uint64_t l = h[heap_addr(c)], x = h[heap_addr(c + 1 <= n ? c + 1 : c)];
+    side.step();
     int s = 0;
     if (c + 1 <= n && !ent_less(ent_of(l), ent_of(x), nodes)) s = 1;
     moved = s ? x : l;
@@ -214,5 +231,9 @@ TSG_HD HeapEnt heap_pop(uint64_t* h, int& n, const int32_t* nodes) {
   }
   heap_st(h, heap_addr(j), last);
   return ret;
+}
+TSG_HD HeapEnt heap_pop(uint64_t* h, int& n, const int32_t* nodes) {
+  HeapNoSide none;
+  return heap_pop(h, n, nodes, none);
 }
 

@@ -522,7 +522,63 @@ extern "C" int tsg_debug_read_stamps(unsigned long long* out_host, int reset) {
 #define CKPT(i)
 #define STAMP_ADD(i, v)
 #endif
-__global__ __launch_bounds__(256) void frontier_kernel(EngineDev D, int superstep) {
+// The look-ups that follow a pop (search.py:281-300: the popped node's record, then its road's successors, label,
+// travel cost and the page of its parent's state row, then the successors' table entries for the futile-expansion
+// check), as the chain that rides along with the sift of heap_pop (tsg_heap.h): three dependent round trips that
+// used to follow the pop's own four now share them.  Values only; every decision stays where it was.
+#ifndef TSG_POP_STAGES
+#define TSG_POP_STAGES 2  // look-up stages that ride inside the sift: 1 = node record + successors etc., 2 = + table entries
+#endif
+struct PopSide {
+  const int32_t* nodes;
+  const int32_t* indices;
+  const int32_t* my_pages;
+  const int32_t* label;
+  const uint8_t* empty_key;
+  const int32_t* cost_tab;
+  const uint64_t* table;
+  int n_roads, allow;
+  int stage;  // 0 idle, 1 node record requested, 2 successors etc. requested, 3 table entries requested / nothing more to do
+  int4 nd0, nd1;
+  int sc[4];
+  int ppage, lab, ekey, cost;
+  uint64_t tq[4];
+  __device__ __forceinline__ void begin(int node) {
+    nd0 = reinterpret_cast<const int4*>(nodes + (size_t)node * ND_WORDS)[0];
+    nd1 = reinterpret_cast<const int4*>(nodes + (size_t)node * ND_WORDS)[1];
+    stage = 1;
+  }
+  __device__ __forceinline__ void step() {
+    if (stage == 1) {
+      if (nd1.x != ND_OPEN) {  // stale duplicate of a closed road: nothing more is looked up
+        stage = 3;
+        return;
+      }
+      const int rid = nd0.x, parent = nd0.y, date_time = nd0.w, beg = nd1.y, C = nd1.z;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) sc[k] = C > 0 ? indices[beg + (k < C ? k : C - 1)] : 0;
+      ppage = parent >= 0 ? my_pages[parent >> TSG_PAGE_SHIFT] : 0;
+      lab = (allow >= 0 && label) ? label[rid] : -1;
+      ekey = (C == 0 && empty_key) ? empty_key[rid] : 0;
+      cost = cost_tab[(size_t)(date_time / 3600) * n_roads + rid];  // search.py:376-381 (<0: per pair)
+      stage = 2;
+    } else if (stage == 2 && TSG_POP_STAGES >= 2) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) tq[k] = table[sc[k]];
+      stage = 3;
+    }
+  }
+  __device__ __forceinline__ void finish() {
+    if (stage == 1) step();
+    if (stage == 2) {  // (with TSG_POP_STAGES == 1 the table entries are always requested here, after the sift)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) tq[k] = table[sc[k]];
+      stage = 3;
+    }
+  }
+};
+
+__global__ __launch_bounds__(256, 3) void frontier_kernel(EngineDev D, int superstep) {
   const int b = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * TSG_SPW + (threadIdx.x & 63);
   if (b >= D.e.slots || (threadIdx.x & 63) >= TSG_SPW) return;
   const tsg_graph& g = D.g;
@@ -879,6 +935,17 @@ __global__ __launch_bounds__(256) void frontier_kernel(EngineDev D, int superste
     // ---- PH_SEARCH: pop until a node can be expanded (search.py:279-300)
     int fin_status = -1, fin_parent = -1, fin_rid = -1, fin_tcode = 0, fin_depth = 0;
     bool yielded = false;
+    PopSide side;
+    side.nodes = nodes;
+    side.indices = g.indices;
+    side.my_pages = my_pages;
+    side.label = g.label;
+    side.empty_key = g.empty_key;
+    side.cost_tab = g.cost;
+    side.table = table;
+    side.n_roads = g.n_roads;
+    side.allow = allow;
+    side.stage = 0;
     while (heap_n > 0 && step < max_step) {
       // The launch lasts as long as its slowest search, and the number of pops a search needs before it
       // finds a node worth expanding has a long tail (stale duplicates, expansions that cannot push
@@ -890,12 +957,13 @@ __global__ __launch_bounds__(256) void frontier_kernel(EngineDev D, int superste
       }
       ++pops_here;
       CKPT(2);
-      const HeapEnt top = heap_pop(heap, heap_n, nodes);
+      side.stage = 0;
+      const HeapEnt top = heap_pop(heap, heap_n, nodes, side);
+      side.finish();
       CKPT(3);  // pop
       STAMP_ADD(13, 1);
       // the node record: rid, parent, log_prob, date_time | state, CSR row of the road, depth
-      const int4 nd0 = reinterpret_cast<const int4*>(nodes + (size_t)top.node * ND_WORDS)[0];
-      const int4 nd1 = reinterpret_cast<const int4*>(nodes + (size_t)top.node * ND_WORDS)[1];
+      const int4 nd0 = side.nd0, nd1 = side.nd1;
       CKPT(4);  // node record
       if (nd1.x != ND_OPEN) continue;  // stale duplicate of a closed rid (search.py:284-287)
       const int rid = nd0.x, parent = nd0.y, nd_lp = nd0.z, date_time = nd0.w;
@@ -915,14 +983,11 @@ __global__ __launch_bounds__(256) void frontier_kernel(EngineDev D, int superste
         fin_depth = depth;
         break;
       }
-      // next round trip: the first successors, the parent's page, the road's label and cost
+      // the first successors, the parent's page, the road's label and cost: requested during the sift (PopSide)
       int sc[4];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) sc[k] = C > 0 ? g.indices[beg + (k < C ? k : C - 1)] : 0;
-      const int ppage = parent >= 0 ? my_pages[parent >> TSG_PAGE_SHIFT] : 0;
-      const int lab = (allow >= 0 && g.label) ? g.label[rid] : -1;
-      const int ekey = (C == 0 && g.empty_key) ? g.empty_key[rid] : 0;
-      const int cost = g.cost[(size_t)(date_time / 3600) * g.n_roads + rid];  // search.py:376-381 (<0: per pair)
+      for (int k = 0; k < 4; ++k) sc[k] = side.sc[k];
+      const int ppage = side.ppage, lab = side.lab, ekey = side.ekey, cost = side.cost;
       const bool gate = C > 0 && (allow < 0 || (g.label && lab == allow));    // search.py:300 / :487
       CKPT(5);  // successors etc
       if (ekey) {  // key present, no successors: `continue` (search.py:993-995)
@@ -954,8 +1019,7 @@ __global__ __launch_bounds__(256) void frontier_kernel(EngineDev D, int superste
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
             const int i = i0 + k < C ? i0 + k : C - 1;
-            const int s = i0 == 0 ? sc[k] : g.indices[beg + i];
-            tq[k] = table[s];
+            tq[k] = i0 == 0 ? side.tq[k] : table[g.indices[beg + i]];  // the first four came with the sift
           }
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
