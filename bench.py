@@ -340,9 +340,10 @@ def classify_differences(searcher, model, od, idx, max_step, lmax, formats=(1, 0
     a, b = runs
     near = unexplained = vanished = 0
     for i in range(len(idx)):
-        if all(torch.equal(a[k][i], b[k][i]) for k in ('rid', 'time', 'len', 'status')):
+        if all(torch.equal(a[k][i], b[k][i]) for k in ('rid', 'time', 'len', 'status', 'steps')):
             vanished += 1          # cannot happen (results do not depend on the batch); counted to be sure
             continue
+        # (a pair may differ in its step count alone: two pops changed places on the way to the same trajectory)
         ka, kb = int(a['poplog_n'][i]), int(b['poplog_n'][i])
         ra, rb = a['poplog_rid'][i, :ka].numpy(), b['poplog_rid'][i, :kb].numpy()
         m = min(ka, kb)

@@ -321,15 +321,22 @@ __global__ __launch_bounds__(256) void score_frontier_kernel(tsg_model m, Engine
   const float inv = 1.0f / acc.l;
 #pragma unroll
   for (int j = 0; j < JT; ++j) pooled[j] = acc.v[j] * inv;
-  // G: the candidates' out_fc rows . pooled (+ bias); the first group is already in registers
+  // G: the candidates' out_fc rows . pooled (+ bias); the first group is already in registers (moved with plain
+  // register copies under a uniform branch: a select between the two arrays made the compiler keep both on the stack)
   float g_logit = -INFINITY;
+  if (w_in_a) {
+#pragma unroll
+    for (int u = 0; u < G; ++u)
+#pragma unroll
+      for (int j = 0; j < JT; ++j) keyB[u][j] = keyA[u][j];
+  }
   {
     float part[G];
 #pragma unroll
     for (int u = 0; u < G; ++u) {
       float p = 0.0f;
 #pragma unroll
-      for (int j = 0; j < JT; ++j) p += (w_in_a ? keyA[u][j] : keyB[u][j]) * pooled[j];
+      for (int j = 0; j < JT; ++j) p += keyB[u][j] * pooled[j];
       part[u] = p;
     }
 #pragma unroll
