@@ -129,7 +129,8 @@ def pmc_traffic(kernel, lstm, rows_per_launch):
         return None, None
     with open(path) as f:
         js = json.load(f)
-    names = {'frontier_kernel': 'frontier_kernel', 'score_frontier_kernel': 'score_frontier_kernel<4, true>',
+    names = {'frontier_kernel': 'frontier_kernel',
+             'score_frontier_kernel': 'score_frontier_kernel<4, %s, true>' % ('true' if lstm == 'split' else 'false'),
              'lstm_layer_kernel[l0]': 'lstm_layer0_split_cand_kernel' if lstm == 'split' else 'lstm_layer_kernel<true>',
              'lstm_layer_kernel[l1]': 'lstm_layer_split_kernel<false>' if lstm == 'split' else 'lstm_layer_kernel<false>'}
     e = js.get(names.get(kernel, kernel))
@@ -454,11 +455,12 @@ def main():
             dist.init_process_group(backend)
         # first contact with the communicator BEFORE the free memory is read and the page pool sized: RCCL creates its
         # channels and workspaces at the first collective of each kind
-        warm = torch.zeros((world, 1 << 16), dtype=torch.int32, device=device)
-        dist.all_reduce(warm[0])
-        dist.all_gather_into_tensor(warm, warm[rank].clone())
+        warm_in = torch.zeros(1 << 16, dtype=torch.int32, device=device)
+        warm_out = torch.zeros(world << 16, dtype=torch.int32, device=device)
+        dist.all_reduce(warm_in)
+        dist.all_gather_into_tensor(warm_out, warm_in)
         torch.cuda.synchronize()
-        del warm
+        del warm_in, warm_out
     from ts_trajgen_amd.search import Searcher
     model = to_device(model, cfg, device)
     searcher = Searcher(device, net.adjacent_list, net.rid_gps, net.road_length, net.road_time_distribution)
