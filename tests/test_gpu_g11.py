@@ -26,7 +26,7 @@ RTOL = 1e-4          # north_star: f-scores within 1e-4 relative in fp32
 PREFIX_LENS = (1, 2, 17, 64, 65, 200, 256)
 
 # near-ties recorded on MI355X (deterministic kernels: the counts do not vary from run to run)
-RECORDED_NEAR_TIES = {1: 14, 0: 16}
+RECORDED_NEAR_TIES = {1: 14, 0: 15}
 RECORDED_RELAX_TIES = {1: 2, 0: 2}
 
 
