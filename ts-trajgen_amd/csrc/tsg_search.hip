@@ -3,6 +3,7 @@
 #include <new>
 
 #include "tsg_engine_dev.h"
+#include "tsg_heap.h"
 
 
 // =====================================================================================
@@ -119,6 +120,164 @@ extern "C" int tsg_geodesic_pairs(const double* geo, int32_t n_rows, int32_t n, 
   return 0;
 }
 
+// =====================================================================================
+// relaxation of a scored expansion (search.py:385-419 / 317-350), one search per lane
+// =====================================================================================
+// The words of the expansion whose successors are relaxed and of the search it belongs to.  The relaxation runs
+// at the start of the frontier kernel's next superstep.  TSG_RELAX_IN_SCORE = 1 (measured, not shipped: DESIGN.md
+// section 8.2) moves it to where the log-probs are, lane 0 of the scoring wave that has just produced them; the
+// frontier kernel then keeps this code for the expansions the scoring wave leaves alone (a workspace cap in reach:
+// the error path lives there).  Results are identical either way (same operations in the same order per search);
+// the frontier launch gets 15 us shorter and the scoring launch 14-18 us longer, because a scoring wave's life is
+// what bounds that launch (four rounds of waves) and the chain of pushes is added to every life.
+#ifndef TSG_RELAX_IN_SCORE
+#define TSG_RELAX_IN_SCORE 0
+#endif
+struct RelaxCtx {
+  int b, e, C, rid, date_time, cost, child_depth, gen, woff, deflen;
+  float best_lp;
+  int heap_n, node_n, err;
+  int heap_room, node_cap, n_roads;
+  uint64_t* heap;
+  uint64_t* table;
+  int32_t* nodes;
+  int32_t* S;
+  const int32_t* pair_cost;
+};
+// successors i0 .. i0+3 of the list (positions >= C repeat the last one and are skipped): ids, scored log-probs,
+// their table entries and CSR rows as fetched by the caller; the pushes stay in list order (search.py:385)
+__device__ __forceinline__ void relax_batch(RelaxCtx& r, int i0, const int cc[4], const float lps[4], uint64_t tt[4],
+                                            const int cb[4], const int ce[4]) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (i0 + k >= r.C || r.err) continue;
+    const int c = cc[k];
+    const float lp = lps[k];
+    bool dup = false;  // the same road twice in one list: re-read what the earlier entry may have changed
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (j < k && cc[j] == c) dup = true;
+    if (dup) tt[k] = r.table[c];
+    // travel time of the expanded road (search.py:376-382); region graphs fall back to a per-pair
+    // cost when the region's time distribution is unknown (search.py:1073-1078)
+    const int cost = r.cost >= 0 ? r.cost : r.pair_cost[(size_t)r.rid * r.n_roads + c];
+    const int next_time = (r.date_time + cost) % 86400;
+    const int tcode_child = next_time / 60 + r.woff;
+    const uint32_t t = (uint32_t)tt[k];
+    const float tlp = __uint_as_float((uint32_t)(tt[k] >> 32));  // open: the node's log_prob; closed: +inf
+    bool pushed = false;
+    int idx = -1;
+    if ((int)(t >> TSG_GEN_SHIFT) != r.gen) {  // c not in rid2node and not in close_set
+      if (r.node_n >= r.node_cap || r.heap_n >= r.heap_room) {
+        r.err = 1;
+        continue;
+      }
+      idx = r.node_n++;
+      int4* nd = reinterpret_cast<int4*>(r.nodes + (size_t)idx * ND_WORDS);
+      nd[0] = make_int4(c, r.e, __float_as_int(lp), next_time);
+      nd[1] = make_int4(ND_OPEN, cb[k], ce[k] - cb[k], r.child_depth);
+      pushed = true;
+    } else {
+      idx = (int)(t & TSG_NODE_MASK);
+      if (tlp < lp) {  // c in rid2node, strictly better
+        if (r.heap_n >= r.heap_room) {
+          r.err = 1;
+          continue;
+        }
+        int32_t* nd = r.nodes + (size_t)idx * ND_WORDS;
+        nd[ND_PARENT] = r.e;
+        nd[ND_LP] = __float_as_int(lp);
+        nd[ND_DATE_TIME] = next_time;
+        nd[ND_DEPTH] = r.child_depth;
+        pushed = true;
+      }
+    }
+    if (pushed) {
+      r.table[c] = (uint64_t)(((uint32_t)r.gen << TSG_GEN_SHIFT) | (uint32_t)idx) | ((uint64_t)__float_as_uint(lp) << 32);
+      HeapEnt he;
+      he.prio = -lp;
+      he.node = idx;
+      heap_push(r.heap, r.heap_n, he, r.nodes);
+      // default-length fallback snapshot (search.py:397-402): np.exp(lp) > best_score, best_score starts at 0
+      if (r.child_depth == r.deflen && lp > r.best_lp && lp > -745.13f) {
+        r.best_lp = lp;
+        r.S[SS_BEST_LP] = __float_as_int(lp);
+        r.S[SS_BEST_PARENT] = r.e;
+        r.S[SS_BEST_RID] = c;
+        r.S[SS_BEST_TCODE] = tcode_child;
+        r.S[SS_HAVE_BEST] = 1;
+      }
+    }
+  }
+}
+
+// The relaxation as the tail of a scoring wave: lane 0 runs the chain.  What it needs was requested while the key
+// rows travelled and waits in three registers: `s_word`, lane i < SS_WORDS = word i of the slot state as the
+// frontier kernel left it; (`pa`, `pb`), lanes 0-3 = the table entries of the first four successors, lanes 4-7 =
+// their CSR rows (indptr[c], indptr[c + 1]).  Lane k < C holds successor k's id and scored log-prob.  Nothing is
+// done (the frontier kernel relaxes as it always did) unless the slot waits for exactly this expansion and every
+// push is certain to find room.
+__device__ __forceinline__ void relax_in_wave(const EngineDev& D, int b, int C, int lane, int my_cand, float my_lp,
+                                              int s_word, unsigned pa, unsigned pb) {
+  const int heap_room = tsg_heap_room(D.e.heap_cap);
+  const int phase = __shfl(s_word, SS_PHASE, TSG_WAVE), heap_n = __shfl(s_word, SS_HEAP_N, TSG_WAVE);
+  const int node_n = __shfl(s_word, SS_NODE_N, TSG_WAVE), cur_c = __shfl(s_word, SS_CUR_C, TSG_WAVE);
+  if (phase != PH_EXPANDED || cur_c != C || C < 1) return;
+  if (node_n + C > D.e.node_cap || heap_n + C > heap_room) return;
+  RelaxCtx r;
+  r.b = b;
+  r.e = __shfl(s_word, SS_CUR_EXP, TSG_WAVE);
+  r.C = C;
+  r.rid = __shfl(s_word, SS_CUR_RID, TSG_WAVE);
+  r.date_time = __shfl(s_word, SS_CUR_DATE_TIME, TSG_WAVE);
+  r.cost = __shfl(s_word, SS_CUR_COST, TSG_WAVE);
+  r.child_depth = __shfl(s_word, SS_CUR_DEPTH, TSG_WAVE) + 1;
+  r.gen = __shfl(s_word, SS_GEN, TSG_WAVE);
+  r.woff = __shfl(s_word, SS_WOFF, TSG_WAVE);
+  r.deflen = __shfl(s_word, SS_DEFLEN, TSG_WAVE);
+  r.best_lp = __int_as_float(__shfl(s_word, SS_BEST_LP, TSG_WAVE));
+  r.heap_n = heap_n;
+  r.node_n = node_n;
+  r.err = 0;
+  r.heap_room = heap_room;
+  r.node_cap = D.e.node_cap;
+  r.n_roads = D.g.n_roads;
+  r.heap = D.e.heap + (size_t)b * D.e.heap_cap;
+  r.table = D.e.table + (size_t)b * D.g.n_roads;
+  r.nodes = D.e.nodes + (size_t)b * D.e.node_cap * ND_WORDS;
+  r.S = D.e.slot_state + (size_t)b * SS_WORDS;
+  r.pair_cost = D.g.pair_cost;
+  const float lp_parent = __int_as_float(__shfl(s_word, SS_CUR_LP, TSG_WAVE));
+  const int step = __shfl(s_word, SS_STEP, TSG_WAVE);
+  for (int i0 = 0; i0 < C; i0 += 4) {
+    int cc[4], cb[4], ce[4];
+    float lps[4];
+    uint64_t tt[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {  // all lanes: lane 0 receives what the other lanes hold
+      const int src = i0 + k < C ? i0 + k : C - 1;
+      cc[k] = __shfl(my_cand, src, TSG_WAVE);
+      lps[k] = C == 1 ? lp_parent : __shfl(my_lp, src, TSG_WAVE);
+      const int kk = k < C ? k : C - 1;
+      tt[k] = (uint64_t)(unsigned)__shfl((int)pa, kk, TSG_WAVE) | ((uint64_t)(unsigned)__shfl((int)pb, kk, TSG_WAVE) << 32);
+      cb[k] = __shfl((int)pa, 4 + kk, TSG_WAVE);
+      ce[k] = __shfl((int)pb, 4 + kk, TSG_WAVE);
+    }
+    if (lane == 0) {
+      if (i0 > 0) {  // beyond the first four (rare): fetched now, after the pushes that may have changed them
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          tt[k] = r.table[cc[k]];
+          cb[k] = D.g.indptr[cc[k]];
+          ce[k] = D.g.indptr[cc[k] + 1];
+        }
+      }
+      relax_batch(r, i0, cc, lps, tt, cb, ce);
+    }
+  }
+  if (lane == 0) *reinterpret_cast<int4*>(r.S) = make_int4(PH_SEARCH, step, r.heap_n, r.node_n);
+}
+
 // Waves per workgroup of the two kernels whose waves run for very different times (a long ancestor chain, a long
 // pop chain): a workgroup gives its registers back only when its last wave ends, so one wave per workgroup
 // lets the next work item start as soon as ANY wave ends (scoring kernel: 130 -> 115 us per launch).
@@ -223,9 +382,33 @@ __global__ __launch_bounds__(256) void score_frontier_kernel(tsg_model m, Engine
 #pragma unroll
     for (int j = 0; j < TSG_H_HIDDEN; ++j) pt[j] = ptp[j];
   }
+#if TSG_RELAX_IN_SCORE
+  if (ncand == 1 && lane == 0) my_cand = D.e.cand_id[(size_t)b * md];
+  const int s_word = D.e.slot_state[(size_t)b * SS_WORDS + (lane < SS_WORDS ? lane : 0)];  // for the relaxation at the end
+#endif
   asm volatile("" : "+v"(mine), "+v"(my_cand));
   anc[(size_t)e * LV + lane] = mine;
+#if TSG_RELAX_IN_SCORE
+  // the first successors' table entries (lanes 0-3) and CSR rows (lanes 4-7), for the relaxation: requested here,
+  // used at the end
+  unsigned pa = 0, pb = 0;
+  {
+    const int k = lane & 3;
+    const int c = __shfl(my_cand, k < ncand ? k : 0, TSG_WAVE);
+    if (lane < 8 && k < ncand) {
+      const unsigned* src = lane < 4 ? reinterpret_cast<const unsigned*>(D.e.table + (size_t)b * D.g.n_roads + c)
+                                     : reinterpret_cast<const unsigned*>(D.g.indptr + c);
+      pa = src[0];
+      pb = src[1];
+    }
+  }
+  if (!scored) {
+    if (ncand == 1) relax_in_wave(D, b, 1, lane, my_cand, 0.0f, s_word, pa, pb);
+    return;
+  }
+#else
   if (!scored) return;
+#endif
   // Round trip 3: function H's candidate rows and the out_fc bias (they need the successor id) go out in front of
   // the first group of key rows; H's score is finished before the attention loop is entered and costs one
   // register from there on.
@@ -364,7 +547,11 @@ __global__ __launch_bounds__(256) void score_frontier_kernel(tsg_model m, Engine
       if (lane == c0 + u && c0 + u < ncand) g_logit = part[u] + out_bias;
   }
   const float f = tsg_mix_softmax(m, g_logit, h_logit, on, nullptr, nullptr);
-  if (on) D.e.cand_lp[(size_t)b * md + lane] = logf(f) + lp_parent;  // search.py:370-373
+  const float my_lp = logf(f) + lp_parent;  // search.py:370-373
+  if (on) D.e.cand_lp[(size_t)b * md + lane] = my_lp;
+#if TSG_RELAX_IN_SCORE
+  relax_in_wave(D, b, ncand, lane, my_cand, my_lp, s_word, pa, pb);
+#endif
 }
 
 // With the split-f16 recurrence the candidate distances (and the control step) ride on the layer-0 launch as extra
@@ -412,8 +599,6 @@ static void launch_score_frontier(const tsg_model* m, const EngineDev& D, int su
 //     two round trips, instead of walking the parent chain one point at a time.
 // (One WAVE per search cuts the round trips further, to 10-14 per superstep, but 24 576 waves of ~1 900
 // instructions are issue-bound: 90 us per launch against this kernel's time; ablate/frontier_wave_per_search.hip.txt.)
-#include "tsg_heap.h"
-
 // A trajectory out of the expansion records of one search: (rid, tcode) is its last point (depth = its length),
 // `parent` the expanded node before it; the chain of parents fills the positions in front (search.py:291-296:
 // the popped node's trace; :421-424: the fallback trace).  Positions >= lmax are dropped.
@@ -601,6 +786,7 @@ __global__ __launch_bounds__(256, 3) void frontier_kernel(EngineDev D, int super
   const int ss_now = pc[PC_SUPERSTEP];
   const int tail_snap = pc[PC_TAIL_SNAP], rtail_snap = pc[PC_RTAIL_SNAP];
   const int abort_level = pc[PC_ABORT_LEVEL];
+#if !TSG_RELAX_IN_SCORE
   int cc0[4];
   float lp0[4];
 #pragma unroll
@@ -609,6 +795,7 @@ __global__ __launch_bounds__(256, 3) void frontier_kernel(EngineDev D, int super
     cc0[k] = D.e.cand_id[(size_t)b * md + i];
     lp0[k] = D.e.cand_lp[(size_t)b * md + i];
   }
+#endif
   // the plane of item_counts this launch fills (superstep parity), for the kernels that follow; nothing reads
   // the word during this launch
   if (b == 0) pc[PC_ITEM_PLANE] = ss_now & 1;
@@ -696,15 +883,37 @@ __global__ __launch_bounds__(256, 3) void frontier_kernel(EngineDev D, int super
     reinterpret_cast<uint32_t*>(table + rid)[1] = 0x7f800000u;
   };
 
-  // ---- relax the expansion scored during the previous superstep (search.py:385-419 / 317-350)
+  // ---- relax the expansion scored during the previous superstep (search.py:385-419 / 317-350), unless the scoring
+  // wave has done it already (it then left PH_SEARCH behind)
   if (phase == PH_EXPANDED) {
-    const int e = cur_exp, C = cur_c, rid = cur_rid;
+    RelaxCtx r;
+    r.b = b;
+    r.e = cur_exp;
+    r.C = cur_c;
+    r.rid = cur_rid;
+    r.date_time = cur_date_time;
+    r.cost = cur_cost;
+    r.child_depth = cur_depth + 1;
+    r.gen = gen;
+    r.woff = woff;
+    r.deflen = deflen;
+    r.best_lp = best_lp_in;
+    r.heap_n = heap_n;
+    r.node_n = node_n;
+    r.err = 0;
+    r.heap_room = heap_room;
+    r.node_cap = D.e.node_cap;
+    r.n_roads = g.n_roads;
+    r.heap = heap;
+    r.table = table;
+    r.nodes = nodes;
+    r.S = S;
+    r.pair_cost = g.pair_cost;
+    const int C = cur_c;
     const float lp_parent = __int_as_float(cur_lp);
-    const int child_depth = cur_depth + 1;
-    float best_lp = best_lp_in;
-    for (int i0 = 0; i0 < C && !err; i0 += 4) {
+    for (int i0 = 0; i0 < C && !r.err; i0 += 4) {
       // the table entries (and CSR rows, for the nodes that turn out new) of up to four successors are fetched
-      // together; the pushes themselves stay in list order (search.py:385)
+      // together
       int cc[4];
       float lps[4];
       uint64_t tt[4];
@@ -712,13 +921,15 @@ __global__ __launch_bounds__(256, 3) void frontier_kernel(EngineDev D, int super
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const int i = i0 + k < C ? i0 + k : C - 1;
-        if (i0 == 0) {
+#if !TSG_RELAX_IN_SCORE
+        if (i0 == 0) {  // came with the slot state
           cc[k] = cc0[k < C ? k : C - 1];
           lps[k] = (C == 1) ? lp_parent : lp0[k < C ? k : C - 1];
-        } else {
-          cc[k] = D.e.cand_id[(size_t)b * md + i];
-          lps[k] = D.e.cand_lp[(size_t)b * md + i];
+          continue;
         }
+#endif
+        cc[k] = D.e.cand_id[(size_t)b * md + i];
+        lps[k] = (C == 1) ? lp_parent : D.e.cand_lp[(size_t)b * md + i];
       }
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
@@ -726,75 +937,11 @@ __global__ __launch_bounds__(256, 3) void frontier_kernel(EngineDev D, int super
         cb[k] = g.indptr[cc[k]];
         ce[k] = g.indptr[cc[k] + 1];
       }
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        if (i0 + k >= C || err) continue;
-        const int c = cc[k];
-        const float lp = lps[k];
-        bool dup = false;  // the same road twice in one list: re-read what the earlier entry may have changed
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (j < k && cc[j] == c) dup = true;
-        if (dup) tt[k] = table[c];
-        // travel time of the expanded road (search.py:376-382); region graphs fall back to a per-pair
-        // cost when the region's time distribution is unknown (search.py:1073-1078)
-        const int cost = cur_cost >= 0 ? cur_cost : g.pair_cost[(size_t)rid * g.n_roads + c];
-        const int next_time = (cur_date_time + cost) % 86400;
-        const int tcode_child = next_time / 60 + woff;
-        const uint32_t t = (uint32_t)tt[k];
-#if TSG_STAMP
-        if (k == 0 && i0 == 0 && t != 0xffffffffu) CKPT(16);  // table entries arrived
-#endif
-        const float tlp = __uint_as_float((uint32_t)(tt[k] >> 32));  // open: the node's log_prob; closed: +inf
-        bool pushed = false;
-        int idx = -1;
-        if ((int)(t >> TSG_GEN_SHIFT) != gen) {  // c not in rid2node and not in close_set
-          if (node_n >= D.e.node_cap || heap_n >= heap_room) {
-            err = 1;
-            continue;
-          }
-          idx = node_n++;
-          int4* nd = reinterpret_cast<int4*>(nodes + (size_t)idx * ND_WORDS);
-          nd[0] = make_int4(c, e, __float_as_int(lp), next_time);
-          nd[1] = make_int4(ND_OPEN, cb[k], ce[k] - cb[k], child_depth);
-          pushed = true;
-        } else {
-          idx = (int)(t & TSG_NODE_MASK);
-          if (tlp < lp) {  // c in rid2node, strictly better
-            if (heap_n >= heap_room) {
-              err = 1;
-              continue;
-            }
-            int32_t* nd = nodes + (size_t)idx * ND_WORDS;
-            nd[ND_PARENT] = e;
-            nd[ND_LP] = __float_as_int(lp);
-            nd[ND_DATE_TIME] = next_time;
-            nd[ND_DEPTH] = child_depth;
-            pushed = true;
-          }
-        }
-        if (pushed) {
-          table[c] = (uint64_t)(((uint32_t)gen << TSG_GEN_SHIFT) | (uint32_t)idx) | ((uint64_t)__float_as_uint(lp) << 32);
-          HeapEnt he;
-          he.prio = -lp;
-          he.node = idx;
-#if TSG_STAMP
-          { int _mv = 0; const long long _a = clock64(); heap_push(heap, heap_n, he, nodes, &_mv); st_acc[19] += _mv; st_acc[20] += heap_n; const long long _b = clock64(); st_acc[17] += _b - _a; st_acc[18] += 1; st_last = _b; }
-#else
-          heap_push(heap, heap_n, he, nodes);
-#endif
-          // default-length fallback snapshot (search.py:397-402): np.exp(lp) > best_score, best_score starts at 0
-          if (child_depth == deflen && lp > best_lp && lp > -745.13f) {
-            best_lp = lp;
-            S[SS_BEST_LP] = __float_as_int(lp);
-            S[SS_BEST_PARENT] = e;
-            S[SS_BEST_RID] = c;
-            S[SS_BEST_TCODE] = tcode_child;
-            S[SS_HAVE_BEST] = 1;
-          }
-        }
-      }
+      relax_batch(r, i0, cc, lps, tt, cb, ce);
     }
+    heap_n = r.heap_n;
+    node_n = r.node_n;
+    err = r.err;
     phase = PH_SEARCH;
     CKPT(1);  // relax
     STAMP_ADD(12, 1);
