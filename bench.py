@@ -656,6 +656,13 @@ def main():
                                            if st32['prof_launches'][i] else None) for i, nm in enumerate(names)},
                     'identical_to_split': int(n_local - len(differ)), 'od_pairs': int(n_local),
                     'differing': int(len(differ))}
+            # layer 1 against the fp32 matrix-core peak (MI355X_MICROARCH.md): rows x 4hp x 2hp x 2 per launch
+            t_l1 = fp32['kernel_avg_us'].get('lstm_layer_kernel[l1]')
+            if t_l1 and st32['prof_launches'][0]:
+                rows32 = st32['prof_items'] / st32['prof_launches'][0]
+                tf = rows32 * 2.0 * 4 * hp * 2 * hp / (t_l1 * 1e-6) / 1e12
+                fp32['layer1_mfma'] = {'achieved': tf, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                                       'frac': tf / PEAK_F32_MFMA_TFLOPS}
             if 0 < len(differ) <= 4096:
                 fp32.update(classify_differences(searcher, model, od, differ, args.max_step, args.lmax))
         two = None
